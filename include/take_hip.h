@@ -1,0 +1,259 @@
+/*
+ * take_hip.h — C ABI of the MI355X path-tracing core (libtake_hip.so).
+ *
+ * This is the drop-in boundary for TaKe's hot path.  The reference has no FFI; the
+ * seam is the C++ function `Image3 render(const std::vector<std::string>&)`
+ * (reference src/render.h:5).  Everything between `build_bvh(scene)`
+ * (src/render.cpp:49) and the end of the `parallel_for` tile loop
+ * (src/render.cpp:59-82) is replaced by the calls below; the XML parser, the
+ * `Scene` aggregate (src/scene.h:13-33) and `imwrite` (src/image.cpp:135) stay
+ * on the host.  The flattening of a reference `Scene` into a `TakeSceneDesc` is
+ * `take_amd/host/take_flatten.hpp`; INTEGRATION.md shows the 20-line patch to
+ * src/render.cpp.
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Every entry point
+ * returns 0 on success or a negative TAKE_E_* code and records a message that
+ * `take_hip_last_error()` returns (thread-local).  Host arrays in a
+ * `TakeSceneDesc` are caller-owned and only read during `take_hip_scene_create`.
+ * Handles are library-owned.  Calls are synchronous unless they take a stream.
+ * One scene handle lives on one GPU (the current HIP device at create time); a
+ * multi-GPU job is one process per GPU, each with its own handle (scene
+ * replicated), rows sharded with `strip_first/strip_stride`.
+ */
+#ifndef TAKE_HIP_H
+#define TAKE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAKE_HIP_ABI_VERSION 1
+
+/* error codes */
+#define TAKE_OK 0
+#define TAKE_E_INVALID (-1)   /* bad argument / malformed scene description   */
+#define TAKE_E_DEVICE (-2)    /* HIP runtime error (message holds hipGetErrorString) */
+#define TAKE_E_NO_GPU (-3)    /* no HIP device: the library never falls back to the CPU */
+#define TAKE_E_NOMEM (-4)
+
+/* Material tags: the alternative index of reference `Material`
+ * (src/material.h:82-93), in declaration order. */
+enum TakeMaterialTag {
+    TAKE_MAT_DIFFUSE = 0,
+    TAKE_MAT_MIRROR = 1,
+    TAKE_MAT_PLASTIC = 2,
+    TAKE_MAT_PHONG = 3,
+    TAKE_MAT_BLINN_PHONG = 4,
+    TAKE_MAT_BLINN_PHONG_MICROFACET = 5,
+    TAKE_MAT_DISNEY_DIFFUSE = 6,
+    TAKE_MAT_DISNEY_METAL = 7,
+    TAKE_MAT_DISNEY_GLASS = 8,
+    TAKE_MAT_DISNEY_CLEARCOAT = 9,
+    TAKE_MAT_DISNEY_SHEEN = 10,
+    TAKE_MAT_DISNEY_BSDF = 11,
+    TAKE_MAT_COUNT = 12
+};
+
+/* reference `Texture = variant<ConstTexture, ImageTexture>` (src/texture.h:16-27) */
+typedef struct TakeTexture {
+    int32_t kind;      /* 0 = ConstTexture, 1 = ImageTexture */
+    int32_t image_id;  /* index into TakeSceneDesc.images (ImageTexture::texture_id) */
+    double value[3];   /* ConstTexture::value */
+    double uscale, vscale, uoffset, voffset;
+} TakeTexture;
+
+/* One alternative of reference `Material`.  `param[]` meaning by tag:
+ *   MIRROR, PLASTIC:            param[0] = eta
+ *   PHONG, BLINN_PHONG, _MICROFACET: param[0] = exponent
+ *   DISNEY_DIFFUSE:             param[0] = roughness, param[1] = subsurface
+ *   others:                     unused on the path (src/materials/disney_*.inl are
+ *                               Lambert clones; CLEARCOAT evaluates to zero).     */
+typedef struct TakeMaterial {
+    int32_t tag;
+    int32_t reserved;
+    TakeTexture reflectance;
+    double param[4];
+} TakeMaterial;
+
+/* reference `Image3` (src/image.h:13-39): texel (x,y) at data[(y*width+x)*3 + c] */
+typedef struct TakeImage3 {
+    int32_t width, height;
+    const double *data;
+} TakeImage3;
+
+/* reference `TriangleMesh` (src/shape.h:13-18) */
+typedef struct TakeMesh {
+    int64_t n_vertices;
+    int64_t n_faces;
+    const double *positions; /* n_vertices * 3 */
+    const int32_t *indices;  /* n_faces * 3 */
+    const double *normals;   /* n_vertices * 3, or NULL (mesh.normals.empty()) */
+    const double *uvs;       /* n_vertices * 2, or NULL (mesh.uvs.empty())     */
+    int32_t material_id;
+    int32_t reserved;
+} TakeMesh;
+
+/* reference `Sphere` (src/shape.h:20-23) */
+typedef struct TakeSphere {
+    double center[3];
+    double radius;
+    int32_t material_id;
+    int32_t reserved;
+} TakeSphere;
+
+/* reference `Light = variant<PointLight, DiffuseAreaLight>` (src/light.h:9-19) */
+typedef struct TakeLight {
+    int32_t kind;      /* 0 = PointLight (counts toward N, contributes nothing:
+                          src/integrator/path_tracing.h:33), 1 = DiffuseAreaLight */
+    int32_t shape_id;  /* DiffuseAreaLight::shape_id (index into the shape arrays) */
+    double intensity[3];
+    double position[3];
+} TakeLight;
+
+/* reference `Camera` (src/camera.h:5-11) */
+typedef struct TakeCamera {
+    int32_t width, height;
+    double lookfrom[3], lookat[3], up[3];
+    double vfov;
+} TakeCamera;
+
+/* Flattened reference `Scene` (src/scene.h:13-33).  The shape arrays are
+ * `scene.shapes` in order (index = BVH primitive id = DiffuseAreaLight::shape_id),
+ * as SoA:  kind 0 = Sphere (ref = index into spheres), 1 = Triangle (ref = mesh id,
+ * face = face id).  area_light = ShapeBase::area_light_id (-1 if none).           */
+typedef struct TakeSceneDesc {
+    TakeCamera camera;
+    double background[3];
+    int32_t n_meshes;
+    int32_t n_spheres;
+    const TakeMesh *meshes;
+    const TakeSphere *spheres;
+    int64_t n_shapes;
+    const int32_t *shape_kind;
+    const int32_t *shape_ref;
+    const int32_t *shape_face;
+    const int32_t *shape_area_light;
+    int32_t n_lights;
+    int32_t n_materials;
+    const TakeLight *lights;
+    const TakeMaterial *materials;
+    int32_t n_images;
+    int32_t reserved;
+    const TakeImage3 *images;
+} TakeSceneDesc;
+
+#define TAKE_PRECISION_F32 0
+#define TAKE_PRECISION_F64 1
+
+/* scene_create options */
+typedef struct TakeBuildOpts {
+    int32_t precision;     /* TAKE_PRECISION_F32 (production) or _F64 (parity mode) */
+    int32_t bvh_threads;   /* host threads for the BVH build; <=0: hardware_concurrency */
+    int32_t max_leaf_size; /* primitives per leaf, 1..4; <=0: default                 */
+    int32_t reserved;
+} TakeBuildOpts;
+
+/* render options: `scene.options` (src/scene.h:8-11) + what the reference
+ * hard-codes in src/render.cpp. */
+typedef struct TakeRenderOpts {
+    int32_t spp;           /* RenderOptions::spp                                      */
+    int32_t max_depth;     /* RenderOptions::max_depth; loop is i <= max_depth         */
+    uint64_t seed;         /* global seed of the counter RNG (replaces the unseedable
+                              std::random_device at src/render.cpp:60)                 */
+    double ray_epsilon;    /* ray tmin / shadow-ray shortening (c_EPSILON's role at
+                              src/render.cpp:75, path_tracing.h:53,79); <=0: default
+                              (1e-7 in f64 as the reference, 1e-4 in f32 — the
+                              reference's own commented alternative, src/take.h:31)    */
+    int32_t strip_first;   /* multi-GPU: this rank renders the 16-row strips s with    */
+    int32_t strip_stride;  /*   s % strip_stride == strip_first (1-GPU: 0 and 1)       */
+    int32_t samples_per_batch; /* samples per pixel in flight at once; <=0: auto       */
+    int32_t reserved;
+} TakeRenderOpts;
+
+typedef struct TakeScene TakeScene; /* opaque */
+
+/* ray / hit records of the trace hooks (test + traversal-only benchmark surface;
+ * counterpart of scene_intersect / scene_occluded, src/scene.cpp:25-64).
+ * Real-typed views: f32 scenes take/return the float fields, f64 scenes the doubles. */
+typedef struct TakeRayF {
+    float org[3], tmin, dir[3], tmax;
+} TakeRayF;
+typedef struct TakeRayD {
+    double org[3], tmin, dir[3], tmax;
+} TakeRayD;
+typedef struct TakeHitF {
+    int32_t shape_id; /* -1 = miss */
+    float t, u, v;
+} TakeHitF;
+typedef struct TakeHitD {
+    int32_t shape_id;
+    int32_t reserved;
+    double t, u, v;
+} TakeHitD;
+
+/* work counters of the most recent take_hip_render / trace call on the scene */
+typedef struct TakeCounters {
+    uint64_t samples;        /* camera paths                                      */
+    uint64_t rays_closest;   /* scene_intersect calls                             */
+    uint64_t rays_shadow;    /* scene_occluded calls                              */
+    uint64_t node_visits;    /* wide-BVH interior nodes fetched (counting mode)   */
+    uint64_t prim_tests;     /* ray/triangle + ray/sphere tests (counting mode)   */
+    uint64_t bounces;        /* shade-kernel path iterations                      */
+    double ms_trace_closest; /* summed HIP-event time of the closest-hit kernel   */
+    double ms_trace_shadow;
+    double ms_shade;
+    double ms_other;
+    double ms_total;         /* whole render, first kernel to last                */
+    uint64_t launches_trace_closest;
+    uint64_t launches_trace_shadow;
+    uint64_t node_bytes;     /* bytes of one interior-node fetch in this layout   */
+    uint64_t prim_bytes;     /* bytes of one primitive record                     */
+} TakeCounters;
+
+const char *take_hip_last_error(void);
+int take_hip_abi_version(void);
+/* number of visible HIP devices, or TAKE_E_NO_GPU */
+int take_hip_device_count(void);
+
+/* Replaces build_bvh(scene) (src/scene.cpp:4-23, src/bvh.cpp:8-45) + upload. */
+int take_hip_scene_create(const TakeSceneDesc *desc, const TakeBuildOpts *opts, TakeScene **out);
+int take_hip_scene_destroy(TakeScene *scene);
+
+/* Replaces the parallel_for tile loop of render() (src/render.cpp:59-82) and all it
+ * calls.  rgb_out: this rank's rows only, compacted in increasing image-row order
+ * (n_rows(strip_first, strip_stride) * width * 3 Real), already flipped as
+ * `img(x, height-y-1)` (src/render.cpp:78) and divided by spp.  f32 scenes write
+ * float, f64 scenes write double.  `take_hip_render_rows` returns how many rows. */
+int take_hip_render(TakeScene *scene, const TakeRenderOpts *opts, void *rgb_out_host);
+/* Same, output left in device memory (d_rgb_out = device pointer), enqueued on
+ * `stream` (hipStream_t, NULL = default stream); returns after enqueue + sync. */
+int take_hip_render_device(TakeScene *scene, const TakeRenderOpts *opts, void *d_rgb_out,
+                           void *stream);
+/* rows this rank owns / their image-row indices (rows_out may be NULL) */
+int take_hip_render_rows(const TakeScene *scene, int32_t strip_first, int32_t strip_stride,
+                         int32_t *rows_out);
+
+/* Kernel-level hooks: n rays in host memory -> n hits in host memory. */
+int take_hip_trace_closest(TakeScene *scene, const void *rays, int64_t n, void *hits);
+int take_hip_trace_any(TakeScene *scene, const void *rays, int64_t n, int32_t *occluded);
+/* Device-resident variants for the traversal-only benchmark: rays/hits are device
+ * pointers; `count_mode` != 0 runs the instrumented kernel that fills node_visits /
+ * prim_tests (never timed). */
+int take_hip_trace_closest_device(TakeScene *scene, const void *d_rays, int64_t n, void *d_hits,
+                                  int32_t count_mode, void *stream);
+
+int take_hip_get_counters(const TakeScene *scene, TakeCounters *out);
+/* enable per-kernel HIP-event timing + counting mode for subsequent renders
+ * (bit 0 = event timing, bit 1 = visit counters; both off by default) */
+int take_hip_set_instrumentation(TakeScene *scene, int32_t flags);
+
+/* BVH introspection (tests / DESIGN figures): node count, primitive count, depth */
+int take_hip_scene_stats(const TakeScene *scene, int64_t *n_nodes, int64_t *n_prims,
+                         int32_t *depth, int64_t *device_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAKE_HIP_H */
