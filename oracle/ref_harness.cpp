@@ -209,7 +209,7 @@ int main(int argc, char **argv) {
     if (cmd == "material") {
         // in (27): tag, color3, p0, p1, geo_n3, sh_n3, uv2, dir_in3, dir_out3, rec_pdf, seed, tex_kind, uscale,vscale,uoff,voff
         //   -> cols 0 | 1..3 | 4 5 | 6..8 | 9..11 | 12 13 | 14..16 | 17..19 | 20 | 21 | 22 | 23..26
-        // out (16): has_rec, rec_dir3, rec_pdf, next_random, eval_sampled3, pdf(dir_in,dir_out), eval_given3 (record{dir_out,rec_pdf}), pdf_sampled_dir
+        // out (14): has_rec, rec_dir3, rec_pdf, next_random, eval_sampled3, pdf(dir_in,dir_out), eval_given3 (record{dir_out,rec_pdf}), pdf_sampled_dir
         // The texture pool holds one fixed procedural 5x4 image (same formula in gen_golden.py).
         auto in = read_f64(argv[2]);
         TexturePool pool;
