@@ -1,0 +1,166 @@
+"""ctypes binding of libtake_hip.so (include/take_hip.h).
+
+The library is the product; this module only marshals.  There is no fallback: if the shared object is
+missing or no HIP device is visible every call raises `TakeError`.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import cdefs as D
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libtake_hip.so")
+_LIB = None
+
+EXPORTS = [
+    "take_hip_last_error", "take_hip_abi_version", "take_hip_device_count", "take_hip_scene_create",
+    "take_hip_scene_destroy", "take_hip_render", "take_hip_render_device", "take_hip_render_rows",
+    "take_hip_trace_closest", "take_hip_trace_any", "take_hip_trace_closest_device", "take_hip_get_counters",
+    "take_hip_set_instrumentation", "take_hip_scene_stats",
+]
+
+
+class TakeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"take_hip error {code}: {msg}")
+        self.code = code
+
+
+def build(force=False):
+    """Compile libtake_hip.so for gfx950 with hipcc (take_amd/csrc/Makefile).  Cross-compiles without a GPU."""
+    src = os.path.join(_PKG, "csrc")
+    args = ["make", "-C", src]
+    if force:
+        args.append("-B")
+    r = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libtake_hip.so failed:\n" + r.stdout[-4000:])
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise TakeError(-3, f"{LIB_PATH} not built (run __graft_entry__.build() / make -C take_amd/csrc)")
+        L = C.CDLL(LIB_PATH)
+        L.take_hip_last_error.restype = C.c_char_p
+        L.take_hip_scene_create.argtypes = [C.POINTER(D.TakeSceneDesc), C.POINTER(D.TakeBuildOpts),
+                                            C.POINTER(C.c_void_p)]
+        L.take_hip_scene_destroy.argtypes = [C.c_void_p]
+        L.take_hip_render.argtypes = [C.c_void_p, C.POINTER(D.TakeRenderOpts), C.c_void_p]
+        L.take_hip_render_device.argtypes = [C.c_void_p, C.POINTER(D.TakeRenderOpts), C.c_void_p, C.c_void_p]
+        L.take_hip_render_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+        L.take_hip_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.take_hip_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]
+        L.take_hip_trace_closest_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
+                                                    C.c_void_p]
+        L.take_hip_get_counters.argtypes = [C.c_void_p, C.POINTER(D.TakeCounters)]
+        L.take_hip_set_instrumentation.argtypes = [C.c_void_p, C.c_int32]
+        L.take_hip_scene_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                           C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc < 0:
+        raise TakeError(rc, lib().take_hip_last_error().decode())
+    return rc
+
+
+def device_count():
+    return _check(lib().take_hip_device_count())
+
+
+class Scene:
+    """A scene resident on the current HIP device: flattened `Scene` + wide BVH in HBM."""
+
+    def __init__(self, scene_data, precision=D.TAKE_PRECISION_F32, bvh_threads=0, max_leaf_size=0):
+        self.sd = scene_data
+        self.precision = precision
+        self.dtype = np.float64 if precision == D.TAKE_PRECISION_F64 else np.float32
+        desc, keep = scene_data.to_desc()
+        opts = D.TakeBuildOpts(precision, bvh_threads, max_leaf_size, 0)
+        h = C.c_void_p()
+        _check(lib().take_hip_scene_create(C.byref(desc), C.byref(opts), C.byref(h)))
+        self.h = h
+        del keep
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().take_hip_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _opts(self, spp, max_depth, seed, ray_epsilon, strip_first, strip_stride, samples_per_batch):
+        o = D.TakeRenderOpts()
+        o.spp, o.max_depth, o.seed, o.ray_epsilon = int(spp), int(max_depth), int(seed), float(ray_epsilon)
+        o.strip_first, o.strip_stride, o.samples_per_batch = int(strip_first), int(strip_stride), int(samples_per_batch)
+        return o
+
+    def rows(self, strip_first=0, strip_stride=1):
+        n = _check(lib().take_hip_render_rows(self.h, strip_first, strip_stride, None))
+        out = (C.c_int32 * max(n, 1))()
+        _check(lib().take_hip_render_rows(self.h, strip_first, strip_stride, out))
+        return np.array(out[:n], np.int32)
+
+    def render(self, spp=None, max_depth=None, seed=0, ray_epsilon=0.0, strip_first=0, strip_stride=1,
+               samples_per_batch=0):
+        """-> (rows, W, 3) image rows owned by this strip set, top row first (host array)."""
+        spp = self.sd.spp if spp is None else spp
+        max_depth = self.sd.max_depth if max_depth is None else max_depth
+        o = self._opts(spp, max_depth, seed, ray_epsilon, strip_first, strip_stride, samples_per_batch)
+        n = _check(lib().take_hip_render_rows(self.h, strip_first, strip_stride, None))
+        out = np.zeros((n, self.sd.width, 3), self.dtype)
+        _check(lib().take_hip_render(self.h, C.byref(o), out.ctypes.data))
+        return out
+
+    def render_device(self, d_ptr, spp, max_depth, seed=0, ray_epsilon=0.0, strip_first=0, strip_stride=1,
+                      samples_per_batch=0, stream=None):
+        """Render into device memory at `d_ptr` (e.g. a torch tensor's data_ptr()); blocks until done."""
+        o = self._opts(spp, max_depth, seed, ray_epsilon, strip_first, strip_stride, samples_per_batch)
+        _check(lib().take_hip_render_device(self.h, C.byref(o), C.c_void_p(d_ptr), C.c_void_p(stream or 0)))
+
+    def trace_closest(self, rays_abi):
+        """rays_abi: (n,8) array in TakeRayF/D layout (org3 tmin dir3 tmax) -> structured hits"""
+        rays = np.ascontiguousarray(rays_abi, self.dtype)
+        n = rays.shape[0]
+        if self.precision == D.TAKE_PRECISION_F64:
+            hits = np.zeros(n, dtype=[("shape_id", "<i4"), ("reserved", "<i4"), ("t", "<f8"), ("u", "<f8"), ("v", "<f8")])
+        else:
+            hits = np.zeros(n, dtype=[("shape_id", "<i4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+        _check(lib().take_hip_trace_closest(self.h, rays.ctypes.data, n, hits.ctypes.data))
+        return hits
+
+    def trace_any(self, rays_abi):
+        rays = np.ascontiguousarray(rays_abi, self.dtype)
+        occ = np.zeros(rays.shape[0], np.int32)
+        _check(lib().take_hip_trace_any(self.h, rays.ctypes.data, rays.shape[0],
+                                        occ.ctypes.data_as(C.POINTER(C.c_int32))))
+        return occ
+
+    def trace_closest_device(self, d_rays, n, d_hits, count_mode=False, stream=None):
+        _check(lib().take_hip_trace_closest_device(self.h, C.c_void_p(d_rays), int(n), C.c_void_p(d_hits),
+                                                   int(count_mode), C.c_void_p(stream or 0)))
+
+    def set_instrumentation(self, timing=False, counting=False):
+        _check(lib().take_hip_set_instrumentation(self.h, (1 if timing else 0) | (2 if counting else 0)))
+
+    def counters(self):
+        c = D.TakeCounters()
+        _check(lib().take_hip_get_counters(self.h, C.byref(c)))
+        return c.as_dict()
+
+    def stats(self):
+        nn, npr, dep, by = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int64()
+        _check(lib().take_hip_scene_stats(self.h, C.byref(nn), C.byref(npr), C.byref(dep), C.byref(by)))
+        return {"n_nodes": nn.value, "n_prims": npr.value, "depth": dep.value, "device_bytes": by.value}

@@ -1,0 +1,586 @@
+// tk_api.hip — implementation of the C ABI of include/take_hip.h: scene upload, the wavefront render loop,
+// the trace hooks.  Host code here only orchestrates: every per-sample operation runs in the kernels of
+// tk_kernels.h.  There is no CPU rendering path in this library: without a HIP device every entry point
+// returns TAKE_E_NO_GPU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "take_hip.h"
+#include "tk_host_scene.h"
+#include "tk_kernels.h"
+
+using namespace tk;
+
+namespace {
+
+thread_local std::string g_error;
+int fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(TAKE_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+    } while (0)
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc((void **)&p, count * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T> &v) {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+struct EventPool {
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    hipEvent_t get() {
+        if (used == ev.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            ev.push_back(e);
+        }
+        return ev[used++];
+    }
+    void reset() { used = 0; }
+    void destroy() {
+        for (auto e : ev) (void)hipEventDestroy(e);
+        ev.clear();
+        used = 0;
+    }
+};
+
+enum TimedKernel { TK_CLOSEST, TK_SHADOW, TK_SHADE, TK_OTHER, TK_NUM };
+
+template <class R> struct SceneT {
+    HostScene<R> host;  // kept: cheap relative to HBM copies, used for stats
+    DevBuf<Node4<R>> nodes;
+    DevBuf<PrimRec<R>> prims;
+    DevBuf<ShapeInfo> shapes;
+    DevBuf<MeshInfo> meshes;
+    DevBuf<int32_t> face_idx;
+    DevBuf<R> normals, uvs, texels;
+    DevBuf<MaterialRec<R>> materials;
+    DevBuf<ImageInfo> images;
+    DevBuf<LightRec<R>> lights;
+    DeviceScene<R> dev{};
+    // render workspace (grown on demand)
+    DevBuf<R> state_r;
+    DevBuf<int32_t> state_i;
+    DevBuf<int32_t> queue[2], shadow_queue, sorted_queue;
+    DevBuf<R> accum, out;
+    DevBuf<int32_t> qwords;  // Q_NUM_WORDS + 2 * N_SORT_KEYS
+    DevBuf<unsigned long long> counters;
+    DevBuf<int2> spill;
+    int64_t capacity = 0;  // path slots allocated
+    int trace_grid = 0;
+
+    size_t scene_bytes() const {
+        return nodes.bytes() + prims.bytes() + shapes.bytes() + meshes.bytes() + face_idx.bytes() + normals.bytes() +
+               uvs.bytes() + texels.bytes() + materials.bytes() + images.bytes() + lights.bytes();
+    }
+    void release() {
+        nodes.release(), prims.release(), shapes.release(), meshes.release(), face_idx.release();
+        normals.release(), uvs.release(), texels.release(), materials.release(), images.release(), lights.release();
+        state_r.release(), state_i.release(), queue[0].release(), queue[1].release(), shadow_queue.release();
+        sorted_queue.release(), accum.release(), out.release(), qwords.release(), counters.release(), spill.release();
+    }
+};
+
+}  // namespace
+
+struct TakeScene {
+    int precision = TAKE_PRECISION_F32;
+    int device = 0;
+    int num_cus = 256;
+    int instrumentation = 0;
+    SceneT<float> f;
+    SceneT<double> d;
+    TakeCounters counters{};
+    EventPool events;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> timed;
+};
+
+namespace {
+
+template <class R> SceneT<R> &pick(TakeScene *s);
+template <> SceneT<float> &pick<float>(TakeScene *s) { return s->f; }
+template <> SceneT<double> &pick<double>(TakeScene *s) { return s->d; }
+
+template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, const TakeBuildOpts &opts) {
+    SceneT<R> &sc = pick<R>(ts);
+    int threads = opts.bvh_threads > 0 ? opts.bvh_threads : (int)std::thread::hardware_concurrency();
+    if (threads <= 0) threads = 1;
+    std::string err = prepare_scene<R>(desc, opts.max_leaf_size, threads, sc.host);
+    if (!err.empty()) return fail(TAKE_E_INVALID, err);
+    const HostScene<R> &h = sc.host;
+    HIP_TRY(sc.nodes.upload(h.nodes));
+    HIP_TRY(sc.prims.upload(h.prims));
+    HIP_TRY(sc.shapes.upload(h.shapes));
+    HIP_TRY(sc.meshes.upload(h.meshes));
+    HIP_TRY(sc.face_idx.upload(h.face_idx));
+    HIP_TRY(sc.normals.upload(h.normals));
+    HIP_TRY(sc.uvs.upload(h.uvs));
+    HIP_TRY(sc.texels.upload(h.texels));
+    HIP_TRY(sc.materials.upload(h.materials));
+    HIP_TRY(sc.images.upload(h.images));
+    HIP_TRY(sc.lights.upload(h.lights));
+    DeviceScene<R> &d = sc.dev;
+    d = h.view();
+    d.nodes = sc.nodes.p;
+    d.prims = sc.prims.p;
+    d.shapes = sc.shapes.p;
+    d.meshes = sc.meshes.p;
+    d.face_idx = sc.face_idx.p;
+    d.normals = sc.normals.p;
+    d.uvs = sc.uvs.p;
+    d.texels = sc.texels.p;
+    d.materials = sc.materials.p;
+    d.images = sc.images.p;
+    d.lights = sc.lights.p;
+    HIP_TRY(sc.qwords.alloc(Q_NUM_WORDS + 2 * N_SORT_KEYS));
+    HIP_TRY(hipMemset(sc.qwords.p, 0, sc.qwords.bytes()));
+    HIP_TRY(sc.counters.alloc(C_NUM_WORDS));
+    HIP_TRY(hipMemset(sc.counters.p, 0, sc.counters.bytes()));
+    // persistent trace grid: resident blocks of the heaviest trace kernel x CUs
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<R, false, false>, BLOCK, 0));
+    per_cu = std::max(1, std::min(per_cu, 8));
+    sc.trace_grid = ts->num_cus * per_cu;
+    HIP_TRY(sc.spill.alloc((size_t)sc.trace_grid * BLOCK * SPILL_STACK));
+    return TAKE_OK;
+}
+
+template <class R> int ensure_workspace(SceneT<R> &sc, int64_t slots, int64_t npix) {
+    if (slots > sc.capacity) {
+        HIP_TRY(sc.state_r.alloc((size_t)S_NUM_R * slots));
+        HIP_TRY(sc.state_i.alloc((size_t)S_NUM_I * slots));
+        HIP_TRY(sc.queue[0].alloc(slots));
+        HIP_TRY(sc.queue[1].alloc(slots));
+        HIP_TRY(sc.shadow_queue.alloc(slots));
+        HIP_TRY(sc.sorted_queue.alloc(slots));
+        sc.capacity = slots;
+    }
+    if ((int64_t)sc.accum.n < 3 * npix) {
+        HIP_TRY(sc.accum.alloc(3 * npix));
+        HIP_TRY(sc.out.alloc(3 * npix));
+    }
+    return TAKE_OK;
+}
+
+__global__ void k_prep(int32_t *q, int next) {
+    const int t = threadIdx.x;
+    if (t == 0) {
+        q[Q_HEAD_CLOSEST] = 0;
+        q[Q_HEAD_SHADOW] = 0;
+        q[Q_N_SHADOW] = 0;
+        q[next ? Q_N_EXT1 : Q_N_EXT0] = 0;
+    }
+    if (t < 2 * N_SORT_KEYS) q[Q_NUM_WORDS + t] = 0;
+}
+__global__ void k_set_word(int32_t *q, int word, int32_t value) { q[word] = value; }
+
+int rows_of(int height, int first, int stride, int32_t *rows_out) {
+    const int n_strips = (height + TILE_ROWS - 1) / TILE_ROWS;
+    int n = 0;
+    std::vector<int> ys;
+    for (int s = first; s < n_strips; s += stride)
+        for (int y = s * TILE_ROWS; y < std::min(height, (s + 1) * TILE_ROWS); y++) ys.push_back(y);
+    n = (int)ys.size();
+    if (rows_out)
+        for (int j = 0; j < n; j++) rows_out[j] = height - 1 - ys[n - 1 - j];  // increasing image row
+    return n;
+}
+
+struct Timer {
+    TakeScene *ts;
+    hipStream_t stream;
+    bool on;
+    void begin(int which) {
+        if (!on) return;
+        hipEvent_t a = ts->events.get(), b = ts->events.get();
+        (void)hipEventRecord(a, stream);
+        ts->timed.push_back({which, {a, b}});
+    }
+    void end() {
+        if (!on) return;
+        (void)hipEventRecord(ts->timed.back().second.second, stream);
+    }
+};
+
+template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void *d_out, hipStream_t stream) {
+    SceneT<R> &sc = pick<R>(ts);
+    const int W = sc.host.cam.width, H = sc.host.cam.height;
+    if (o.spp <= 0) return fail(TAKE_E_INVALID, "spp must be positive");
+    if (o.max_depth < -1) return fail(TAKE_E_INVALID, "max_depth must be >= -1");
+    const int stride = o.strip_stride > 0 ? o.strip_stride : 1;
+    const int first = o.strip_first;
+    if (first < 0 || first >= stride) return fail(TAKE_E_INVALID, "strip_first must be in [0, strip_stride)");
+    const int n_rows = rows_of(H, first, stride, nullptr);
+    const int64_t npix = (int64_t)n_rows * W;
+    ts->counters = TakeCounters{};
+    ts->counters.node_bytes = sizeof(Node4<R>);
+    ts->counters.prim_bytes = sizeof(PrimRec<R>);
+    if (npix == 0) return TAKE_OK;
+    if (npix >= ((int64_t)1 << 30)) return fail(TAKE_E_INVALID, "image too large");
+
+    const int64_t target = (int64_t)8 << 20;  // paths in flight per batch
+    int spb = o.samples_per_batch > 0 ? o.samples_per_batch : (int)std::max<int64_t>(1, target / npix);
+    spb = std::min(spb, o.spp);
+    while ((int64_t)spb * npix >= ((int64_t)1 << 31) - (1 << 26)) spb--;
+    const int64_t slots = (int64_t)spb * npix;
+    int rc = ensure_workspace(sc, slots, npix);
+    if (rc) return rc;
+
+    PathState<R> st{sc.state_r.p, sc.state_i.p, sc.capacity};
+    RenderParams<R> rp{};
+    rp.width = W, rp.height = H, rp.n_local_rows = n_rows, rp.npix = (int32_t)npix;
+    rp.strip_first = first, rp.strip_stride = stride;
+    rp.spp = o.spp, rp.max_depth = o.max_depth, rp.seed = o.seed;
+    rp.ray_eps = o.ray_epsilon > 0 ? R(o.ray_epsilon) : (sizeof(R) == 8 ? R(1e-7) : R(1e-4));
+
+    const bool timing = (ts->instrumentation & 1) != 0;
+    const bool counting = (ts->instrumentation & 2) != 0;
+    const bool sort_materials = sc.host.n_material_tags > 1;
+    ts->events.reset();
+    ts->timed.clear();
+    Timer tm{ts, stream, timing};
+    int32_t *q = sc.qwords.p;
+    int32_t *tag_count = q + Q_NUM_WORDS, *tag_cursor = q + Q_NUM_WORDS + N_SORT_KEYS;
+    StackSpill spill{sc.spill.p, (int64_t)sc.trace_grid * BLOCK};
+    const int wide_grid = (int)std::min<int64_t>((slots + BLOCK - 1) / BLOCK, (int64_t)ts->num_cus * 8);
+    const int pix_grid = (int)std::min<int64_t>((npix + BLOCK - 1) / BLOCK, (int64_t)ts->num_cus * 8);
+
+    HIP_TRY(hipMemsetAsync(sc.accum.p, 0, sizeof(R) * 3 * npix, stream));
+    HIP_TRY(hipMemsetAsync(sc.counters.p, 0, sc.counters.bytes(), stream));
+    hipEvent_t ev_begin = ts->events.get(), ev_end = ts->events.get();
+    HIP_TRY(hipEventRecord(ev_begin, stream));
+
+    for (int s0 = 0; s0 < o.spp; s0 += spb) {
+        const int nb = std::min(spb, o.spp - s0);
+        const int64_t n = (int64_t)nb * npix;
+        rp.s0 = s0;
+        rp.spb = nb;
+        tm.begin(TK_OTHER);
+        hipLaunchKernelGGL((k_generate<R>), dim3(wide_grid), dim3(BLOCK), 0, stream, sc.dev, rp, st, sc.queue[0].p, n);
+        hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, stream, q, (int)Q_N_EXT0, (int32_t)n);
+        tm.end();
+        const int rounds = o.max_depth + 2;
+        for (int k = 0; k < rounds; k++) {
+            const int cur = k & 1, next = cur ^ 1;
+            int32_t *n_cur = q + (cur ? Q_N_EXT1 : Q_N_EXT0), *n_next = q + (next ? Q_N_EXT1 : Q_N_EXT0);
+            hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, stream, q, next);
+            tm.begin(TK_CLOSEST);
+            if (counting)
+                hipLaunchKernelGGL((k_trace<R, false, true>), dim3(sc.trace_grid), dim3(BLOCK), 0, stream, sc.dev, st,
+                                   sc.queue[cur].p, n_cur, q + Q_HEAD_CLOSEST, rp.ray_eps, sc.counters.p, spill);
+            else
+                hipLaunchKernelGGL((k_trace<R, false, false>), dim3(sc.trace_grid), dim3(BLOCK), 0, stream, sc.dev, st,
+                                   sc.queue[cur].p, n_cur, q + Q_HEAD_CLOSEST, rp.ray_eps, sc.counters.p, spill);
+            tm.end();
+            const int32_t *shade_in = sc.queue[cur].p;
+            if (sort_materials) {
+                tm.begin(TK_OTHER);
+                hipLaunchKernelGGL((k_sort_count<R>), dim3(wide_grid), dim3(BLOCK), 0, stream, sc.dev, st,
+                                   sc.queue[cur].p, n_cur, tag_count);
+                hipLaunchKernelGGL((k_sort_scatter<R>), dim3(wide_grid), dim3(BLOCK), 0, stream, sc.dev, st,
+                                   sc.queue[cur].p, n_cur, tag_count, tag_cursor, sc.sorted_queue.p);
+                tm.end();
+                shade_in = sc.sorted_queue.p;
+            }
+            tm.begin(TK_SHADE);
+            hipLaunchKernelGGL((k_shade<R>), dim3(wide_grid), dim3(BLOCK), 0, stream, sc.dev, rp, st, shade_in, n_cur,
+                               sc.queue[next].p, n_next, sc.shadow_queue.p, q + Q_N_SHADOW, k, sc.counters.p);
+            tm.end();
+            if (k <= o.max_depth) {
+                tm.begin(TK_SHADOW);
+                if (counting)
+                    hipLaunchKernelGGL((k_trace<R, true, true>), dim3(sc.trace_grid), dim3(BLOCK), 0, stream, sc.dev,
+                                       st, sc.shadow_queue.p, q + Q_N_SHADOW, q + Q_HEAD_SHADOW, rp.ray_eps,
+                                       sc.counters.p, spill);
+                else
+                    hipLaunchKernelGGL((k_trace<R, true, false>), dim3(sc.trace_grid), dim3(BLOCK), 0, stream, sc.dev,
+                                       st, sc.shadow_queue.p, q + Q_N_SHADOW, q + Q_HEAD_SHADOW, rp.ray_eps,
+                                       sc.counters.p, spill);
+                tm.end();
+            }
+            // every 8 rounds look at the queue length: stop launching once every path of the batch has ended
+            if ((k & 7) == 7 && k + 1 < rounds) {
+                int32_t alive = 0;
+                HIP_TRY(hipMemcpyAsync(&alive, n_next, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (alive == 0) break;
+            }
+        }
+        tm.begin(TK_OTHER);
+        hipLaunchKernelGGL((k_accumulate<R>), dim3(pix_grid), dim3(BLOCK), 0, stream, st, sc.accum.p, (int32_t)npix, nb);
+        tm.end();
+    }
+    tm.begin(TK_OTHER);
+    hipLaunchKernelGGL((k_resolve<R>), dim3(pix_grid), dim3(BLOCK), 0, stream, sc.accum.p, (R *)d_out, W, n_rows, o.spp);
+    tm.end();
+    HIP_TRY(hipEventRecord(ev_end, stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+
+    unsigned long long c[C_NUM_WORDS];
+    HIP_TRY(hipMemcpy(c, sc.counters.p, sizeof c, hipMemcpyDeviceToHost));
+    TakeCounters &tc = ts->counters;
+    tc.samples = (uint64_t)npix * (uint64_t)o.spp;
+    tc.rays_closest = c[C_RAYS_CLOSEST];
+    tc.rays_shadow = c[C_RAYS_SHADOW];
+    tc.node_visits = c[C_NODE_VISITS];
+    tc.prim_tests = c[C_PRIM_TESTS];
+    tc.bounces = c[C_BOUNCES];
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
+    tc.ms_total = ms;
+    double acc[TK_NUM] = {0, 0, 0, 0};
+    for (auto &t : ts->timed) {
+        float m = 0;
+        if (hipEventElapsedTime(&m, t.second.first, t.second.second) == hipSuccess) acc[t.first] += m;
+        if (t.first == TK_CLOSEST) tc.launches_trace_closest++;
+        if (t.first == TK_SHADOW) tc.launches_trace_shadow++;
+    }
+    tc.ms_trace_closest = acc[TK_CLOSEST];
+    tc.ms_trace_shadow = acc[TK_SHADOW];
+    tc.ms_shade = acc[TK_SHADE];
+    tc.ms_other = acc[TK_OTHER];
+    return TAKE_OK;
+}
+
+template <class R>
+int trace_impl(TakeScene *ts, const void *d_rays, int64_t n, void *d_hits, int32_t *d_occ, bool any, bool count,
+               hipStream_t stream) {
+    SceneT<R> &sc = pick<R>(ts);
+    if (n < 0 || n >= ((int64_t)1 << 31) - (1 << 26)) return fail(TAKE_E_INVALID, "ray count out of range");
+    StackSpill spill{sc.spill.p, (int64_t)sc.trace_grid * BLOCK};
+    int32_t *q = sc.qwords.p;
+    HIP_TRY(hipMemsetAsync(q + Q_HEAD_CLOSEST, 0, sizeof(int32_t), stream));
+    HIP_TRY(hipMemsetAsync(sc.counters.p, 0, sc.counters.bytes(), stream));
+    hipEvent_t a = nullptr, b = nullptr;
+    ts->events.reset();
+    a = ts->events.get(), b = ts->events.get();
+    HIP_TRY(hipEventRecord(a, stream));
+    const RayAoS<R> *rays = (const RayAoS<R> *)d_rays;
+    HitAoS<R> *hits = (HitAoS<R> *)d_hits;
+    const dim3 g(sc.trace_grid), bl(BLOCK);
+    if (any) {
+        hipLaunchKernelGGL((k_trace_rays<R, true, false>), g, bl, 0, stream, sc.dev, rays, n, hits, d_occ,
+                           q + Q_HEAD_CLOSEST, sc.counters.p, spill);
+    } else if (count) {
+        hipLaunchKernelGGL((k_trace_rays<R, false, true>), g, bl, 0, stream, sc.dev, rays, n, hits, d_occ,
+                           q + Q_HEAD_CLOSEST, sc.counters.p, spill);
+    } else {
+        hipLaunchKernelGGL((k_trace_rays<R, false, false>), g, bl, 0, stream, sc.dev, rays, n, hits, d_occ,
+                           q + Q_HEAD_CLOSEST, sc.counters.p, spill);
+    }
+    HIP_TRY(hipEventRecord(b, stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+    unsigned long long c[C_NUM_WORDS];
+    HIP_TRY(hipMemcpy(c, sc.counters.p, sizeof c, hipMemcpyDeviceToHost));
+    ts->counters = TakeCounters{};
+    ts->counters.node_bytes = sizeof(Node4<R>);
+    ts->counters.prim_bytes = sizeof(PrimRec<R>);
+    (any ? ts->counters.rays_shadow : ts->counters.rays_closest) = (uint64_t)n;
+    ts->counters.node_visits = c[C_NODE_VISITS];
+    ts->counters.prim_tests = c[C_PRIM_TESTS];
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    (any ? ts->counters.ms_trace_shadow : ts->counters.ms_trace_closest) = ms;
+    (any ? ts->counters.launches_trace_shadow : ts->counters.launches_trace_closest) = 1;
+    ts->counters.ms_total = ms;
+    return TAKE_OK;
+}
+
+template <class R> int trace_host(TakeScene *ts, const void *rays, int64_t n, void *hits, int32_t *occ, bool any) {
+    if (n == 0) return TAKE_OK;
+    DevBuf<RayAoS<R>> d_rays;
+    DevBuf<HitAoS<R>> d_hits;
+    DevBuf<int32_t> d_occ;
+    HIP_TRY(d_rays.alloc(n));
+    int rc = TAKE_OK;
+    do {
+        if (hipMemcpy(d_rays.p, rays, n * sizeof(RayAoS<R>), hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(TAKE_E_DEVICE, "ray upload failed");
+            break;
+        }
+        if (any ? d_occ.alloc(n) != hipSuccess : d_hits.alloc(n) != hipSuccess) {
+            rc = fail(TAKE_E_NOMEM, "hit buffer allocation failed");
+            break;
+        }
+        rc = trace_impl<R>(ts, d_rays.p, n, d_hits.p, d_occ.p, any, false, nullptr);
+        if (rc) break;
+        hipError_t e = any ? hipMemcpy(occ, d_occ.p, n * sizeof(int32_t), hipMemcpyDeviceToHost)
+                           : hipMemcpy(hits, d_hits.p, n * sizeof(HitAoS<R>), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(TAKE_E_DEVICE, "hit download failed");
+    } while (0);
+    d_rays.release(), d_hits.release(), d_occ.release();
+    return rc;
+}
+
+int check_device() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(TAKE_E_NO_GPU, "no HIP device visible: libtake_hip has no CPU path");
+    return n;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *take_hip_last_error(void) { return g_error.c_str(); }
+int take_hip_abi_version(void) { return TAKE_HIP_ABI_VERSION; }
+int take_hip_device_count(void) { return check_device(); }
+
+int take_hip_scene_create(const TakeSceneDesc *desc, const TakeBuildOpts *opts, TakeScene **out) {
+    if (!desc || !out) return fail(TAKE_E_INVALID, "null argument");
+    *out = nullptr;
+    int nd = check_device();
+    if (nd < 0) return nd;
+    TakeBuildOpts o{};
+    if (opts) o = *opts;
+    if (o.precision != TAKE_PRECISION_F32 && o.precision != TAKE_PRECISION_F64)
+        return fail(TAKE_E_INVALID, "unknown precision");
+    TakeScene *ts = new (std::nothrow) TakeScene();
+    if (!ts) return fail(TAKE_E_NOMEM, "out of host memory");
+    ts->precision = o.precision;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&ts->device) != hipSuccess || hipGetDeviceProperties(&prop, ts->device) != hipSuccess) {
+        delete ts;
+        return fail(TAKE_E_DEVICE, "cannot query the HIP device");
+    }
+    ts->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int rc;
+    try {
+        rc = o.precision == TAKE_PRECISION_F64 ? upload_scene<double>(ts, *desc, o) : upload_scene<float>(ts, *desc, o);
+    } catch (const std::bad_alloc &) {
+        rc = fail(TAKE_E_NOMEM, "out of host memory while preparing the scene");
+    } catch (const std::exception &e) {
+        rc = fail(TAKE_E_INVALID, e.what());
+    }
+    if (rc) {
+        ts->f.release();
+        ts->d.release();
+        delete ts;
+        return rc;
+    }
+    *out = ts;
+    return TAKE_OK;
+}
+
+int take_hip_scene_destroy(TakeScene *ts) {
+    if (!ts) return TAKE_OK;
+    ts->f.release();
+    ts->d.release();
+    ts->events.destroy();
+    delete ts;
+    return TAKE_OK;
+}
+
+int take_hip_render_rows(const TakeScene *ts, int32_t strip_first, int32_t strip_stride, int32_t *rows_out) {
+    if (!ts) return fail(TAKE_E_INVALID, "null scene");
+    if (strip_stride <= 0 || strip_first < 0 || strip_first >= strip_stride)
+        return fail(TAKE_E_INVALID, "strip_first must be in [0, strip_stride)");
+    const int H = ts->precision == TAKE_PRECISION_F64 ? ts->d.host.cam.height : ts->f.host.cam.height;
+    return rows_of(H, strip_first, strip_stride, rows_out);
+}
+
+int take_hip_render_device(TakeScene *ts, const TakeRenderOpts *opts, void *d_rgb_out, void *stream) {
+    if (!ts || !opts || !d_rgb_out) return fail(TAKE_E_INVALID, "null argument");
+    if (ts->precision == TAKE_PRECISION_F64) return render_impl<double>(ts, *opts, d_rgb_out, (hipStream_t)stream);
+    return render_impl<float>(ts, *opts, d_rgb_out, (hipStream_t)stream);
+}
+
+int take_hip_render(TakeScene *ts, const TakeRenderOpts *opts, void *rgb_out_host) {
+    if (!ts || !opts || !rgb_out_host) return fail(TAKE_E_INVALID, "null argument");
+    const bool f64 = ts->precision == TAKE_PRECISION_F64;
+    const int W = f64 ? ts->d.host.cam.width : ts->f.host.cam.width;
+    const int stride = opts->strip_stride > 0 ? opts->strip_stride : 1;
+    if (opts->strip_first < 0 || opts->strip_first >= stride)
+        return fail(TAKE_E_INVALID, "strip_first must be in [0, strip_stride)");
+    const int rows = take_hip_render_rows(ts, opts->strip_first, stride, nullptr);
+    if (rows < 0) return rows;
+    const size_t bytes = (size_t)rows * W * 3 * (f64 ? 8 : 4);
+    if (bytes == 0) return TAKE_OK;
+    // render into the scene's own output buffer, then copy out
+    int rc;
+    if (f64) {
+        rc = ensure_workspace(ts->d, 0, (int64_t)rows * W);
+        if (!rc) rc = render_impl<double>(ts, *opts, ts->d.out.p, nullptr);
+        if (!rc) HIP_TRY(hipMemcpy(rgb_out_host, ts->d.out.p, bytes, hipMemcpyDeviceToHost));
+    } else {
+        rc = ensure_workspace(ts->f, 0, (int64_t)rows * W);
+        if (!rc) rc = render_impl<float>(ts, *opts, ts->f.out.p, nullptr);
+        if (!rc) HIP_TRY(hipMemcpy(rgb_out_host, ts->f.out.p, bytes, hipMemcpyDeviceToHost));
+    }
+    return rc;
+}
+
+int take_hip_trace_closest(TakeScene *ts, const void *rays, int64_t n, void *hits) {
+    if (!ts || (n > 0 && (!rays || !hits))) return fail(TAKE_E_INVALID, "null argument");
+    return ts->precision == TAKE_PRECISION_F64 ? trace_host<double>(ts, rays, n, hits, nullptr, false)
+                                               : trace_host<float>(ts, rays, n, hits, nullptr, false);
+}
+int take_hip_trace_any(TakeScene *ts, const void *rays, int64_t n, int32_t *occluded) {
+    if (!ts || (n > 0 && (!rays || !occluded))) return fail(TAKE_E_INVALID, "null argument");
+    return ts->precision == TAKE_PRECISION_F64 ? trace_host<double>(ts, rays, n, nullptr, occluded, true)
+                                               : trace_host<float>(ts, rays, n, nullptr, occluded, true);
+}
+int take_hip_trace_closest_device(TakeScene *ts, const void *d_rays, int64_t n, void *d_hits, int32_t count_mode,
+                                  void *stream) {
+    if (!ts || (n > 0 && (!d_rays || !d_hits))) return fail(TAKE_E_INVALID, "null argument");
+    if (n == 0) return TAKE_OK;
+    return ts->precision == TAKE_PRECISION_F64
+               ? trace_impl<double>(ts, d_rays, n, d_hits, nullptr, false, count_mode != 0, (hipStream_t)stream)
+               : trace_impl<float>(ts, d_rays, n, d_hits, nullptr, false, count_mode != 0, (hipStream_t)stream);
+}
+
+int take_hip_get_counters(const TakeScene *ts, TakeCounters *out) {
+    if (!ts || !out) return fail(TAKE_E_INVALID, "null argument");
+    *out = ts->counters;
+    return TAKE_OK;
+}
+int take_hip_set_instrumentation(TakeScene *ts, int32_t flags) {
+    if (!ts) return fail(TAKE_E_INVALID, "null scene");
+    ts->instrumentation = flags;
+    return TAKE_OK;
+}
+int take_hip_scene_stats(const TakeScene *ts, int64_t *n_nodes, int64_t *n_prims, int32_t *depth,
+                         int64_t *device_bytes) {
+    if (!ts) return fail(TAKE_E_INVALID, "null scene");
+    const bool f64 = ts->precision == TAKE_PRECISION_F64;
+    const WideBvhStats &s = f64 ? ts->d.host.stats : ts->f.host.stats;
+    if (n_nodes) *n_nodes = s.n_nodes;
+    if (n_prims) *n_prims = s.n_prims;
+    if (depth) *depth = s.depth;
+    if (device_bytes) *device_bytes = (int64_t)(f64 ? ts->d.scene_bytes() : ts->f.scene_bytes());
+    return TAKE_OK;
+}
+
+}  // extern "C"

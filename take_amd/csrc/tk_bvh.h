@@ -1,0 +1,273 @@
+// tk_bvh.h — host-side acceleration-structure build: binned-SAH BVH2 -> 4-wide BVH in breadth-first order.
+//
+// Replaces the reference's construct_bvh (src/bvh.cpp:8-45: recursive median split on the largest axis, one
+// primitive per leaf, a full copy of the box vector per level, O(N log^2 N)).  Closest-hit results do not depend
+// on the tree (tk_traverse.h keeps the box test conservative), so the tree is chosen for the GPU:
+//   * surface-area heuristic over 16 centroid bins on all three axes, leaves of up to MAX_LEAF primitives;
+//   * collapsed to 4-wide nodes by repeatedly opening the child with the largest surface area;
+//   * nodes emitted breadth-first (top levels = array prefix), primitives re-ordered into leaf order;
+//   * large subtrees are built by std::async tasks over disjoint index ranges.
+#pragma once
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <future>
+#include <limits>
+#include <thread>
+#include <vector>
+
+#include "tk_scene.h"
+
+namespace tk {
+
+struct BuildPrim {
+    double bmin[3], bmax[3];
+    int32_t id;
+};
+struct Bvh2Node {
+    double bmin[3], bmax[3];
+    int32_t left, right;   // interior
+    int32_t first, count;  // leaf when count > 0 (range in the permuted primitive order)
+};
+
+struct Bounds {
+    double lo[3], hi[3];
+    Bounds() {
+        for (int a = 0; a < 3; a++) lo[a] = std::numeric_limits<double>::infinity(), hi[a] = -lo[a];
+    }
+    void grow(const double *mn, const double *mx) {
+        for (int a = 0; a < 3; a++) lo[a] = std::min(lo[a], mn[a]), hi[a] = std::max(hi[a], mx[a]);
+    }
+    void grow_pt(const double *p) { grow(p, p); }
+    double half_area() const {
+        double e0 = hi[0] - lo[0], e1 = hi[1] - lo[1], e2 = hi[2] - lo[2];
+        if (e0 < 0) return 0.0;
+        return e0 * e1 + e1 * e2 + e2 * e0;
+    }
+};
+
+class Bvh2Builder {
+  public:
+    Bvh2Builder(std::vector<BuildPrim> &prims, int max_leaf, int threads)
+        : prims_(prims), max_leaf_(std::max(1, std::min(max_leaf, (int)MAX_LEAF))), threads_(std::max(1, threads)) {
+        nodes_.resize(std::max<size_t>(1, 2 * prims.size()));
+        next_.store(0);
+    }
+    // returns root index; nodes() valid afterwards
+    int build() {
+        if (prims_.empty()) return -1;
+        int root = alloc();
+        int spawn_depth = 0;
+        while ((1 << spawn_depth) < threads_ * 4) spawn_depth++;
+        build_range(root, 0, (int)prims_.size(), threads_ > 1 ? spawn_depth : 0);
+        nodes_.resize(next_.load());
+        return root;
+    }
+    std::vector<Bvh2Node> &nodes() { return nodes_; }
+
+  private:
+    static constexpr int BINS = 16;
+    std::vector<BuildPrim> &prims_;
+    std::vector<Bvh2Node> nodes_;
+    std::atomic<int> next_;
+    int max_leaf_, threads_;
+
+    int alloc() { return next_.fetch_add(1); }
+
+    void build_range(int node, int lo, int hi, int spawn) {
+        Bounds b, cb;
+        for (int i = lo; i < hi; i++) {
+            b.grow(prims_[i].bmin, prims_[i].bmax);
+            double c[3];
+            for (int a = 0; a < 3; a++) c[a] = 0.5 * (prims_[i].bmin[a] + prims_[i].bmax[a]);
+            cb.grow_pt(c);
+        }
+        Bvh2Node &n = nodes_[node];
+        for (int a = 0; a < 3; a++) n.bmin[a] = b.lo[a], n.bmax[a] = b.hi[a];
+        n.left = n.right = -1;
+        n.first = lo;
+        n.count = 0;
+        const int cnt = hi - lo;
+        if (cnt == 1) {
+            n.count = 1;
+            return;
+        }
+        // binned SAH over the three axes
+        double best_cost = std::numeric_limits<double>::infinity();
+        int best_axis = -1, best_split = -1;
+        for (int a = 0; a < 3; a++) {
+            const double ext = cb.hi[a] - cb.lo[a];
+            if (!(ext > 0)) continue;
+            Bounds bb[BINS];
+            int bc[BINS] = {0};
+            const double scale = BINS / ext;
+            for (int i = lo; i < hi; i++) {
+                double c = 0.5 * (prims_[i].bmin[a] + prims_[i].bmax[a]);
+                int k = std::min(BINS - 1, std::max(0, (int)((c - cb.lo[a]) * scale)));
+                bb[k].grow(prims_[i].bmin, prims_[i].bmax);
+                bc[k]++;
+            }
+            double right_area[BINS];
+            int right_cnt[BINS];
+            Bounds acc;
+            int c = 0;
+            for (int k = BINS - 1; k >= 1; k--) {
+                if (bc[k]) acc.grow(bb[k].lo, bb[k].hi);
+                c += bc[k];
+                right_area[k] = acc.half_area();
+                right_cnt[k] = c;
+            }
+            Bounds accl;
+            int cl = 0;
+            for (int k = 0; k < BINS - 1; k++) {
+                if (bc[k]) accl.grow(bb[k].lo, bb[k].hi);
+                cl += bc[k];
+                if (cl == 0 || right_cnt[k + 1] == 0) continue;
+                // leaves hold up to max_leaf primitives: cost in units of leaf visits keeps leaves full
+                double cost = accl.half_area() * std::ceil(cl / (double)max_leaf_) +
+                              right_area[k + 1] * std::ceil(right_cnt[k + 1] / (double)max_leaf_);
+                if (cost < best_cost) best_cost = cost, best_axis = a, best_split = k;
+            }
+        }
+        if (cnt <= max_leaf_) {
+            // make a leaf unless splitting is clearly cheaper (one node test + two smaller leaves)
+            const double leaf_cost = b.half_area() * 1.0;
+            const double split_cost = best_axis < 0 ? std::numeric_limits<double>::infinity()
+                                                    : 0.5 * b.half_area() + best_cost;
+            if (split_cost >= leaf_cost) {
+                n.count = cnt;
+                return;
+            }
+        }
+        int mid;
+        if (best_axis < 0) {
+            mid = lo + cnt / 2;  // all centroids coincide: split by index
+        } else {
+            const double ext = cb.hi[best_axis] - cb.lo[best_axis];
+            const double scale = BINS / ext;
+            const double clo = cb.lo[best_axis];
+            const int a = best_axis, ks = best_split;
+            auto it = std::partition(prims_.begin() + lo, prims_.begin() + hi, [&](const BuildPrim &p) {
+                double c = 0.5 * (p.bmin[a] + p.bmax[a]);
+                int k = std::min(BINS - 1, std::max(0, (int)((c - clo) * scale)));
+                return k <= ks;
+            });
+            mid = (int)(it - prims_.begin());
+            if (mid == lo || mid == hi) mid = lo + cnt / 2;
+        }
+        const int l = alloc(), r = alloc();
+        nodes_[node].left = l;
+        nodes_[node].right = r;
+        if (spawn > 0 && cnt > 8192) {
+            auto fut = std::async(std::launch::async, [=]() { build_range(l, lo, mid, spawn - 1); });
+            build_range(r, mid, hi, spawn - 1);
+            fut.get();
+        } else {
+            build_range(l, lo, mid, 0);
+            build_range(r, mid, hi, 0);
+        }
+    }
+};
+
+// outward rounding of a double box coordinate to R
+inline float round_down(double x, float) {
+    float f = (float)x;
+    if ((double)f > x) f = std::nextafter(f, -std::numeric_limits<float>::infinity());
+    return f;
+}
+inline float round_up(double x, float) {
+    float f = (float)x;
+    if ((double)f < x) f = std::nextafter(f, std::numeric_limits<float>::infinity());
+    return f;
+}
+inline double round_down(double x, double) { return x; }
+inline double round_up(double x, double) { return x; }
+
+struct WideBvhStats {
+    int64_t n_nodes = 0, n_prims = 0;
+    int depth = 0;
+    double sah = 0;  // expected (node fetches, primitive tests) per random ray, for DESIGN figures
+};
+
+// Collapse a BVH2 into Node4<R> records (breadth-first) and the leaf-ordered primitive permutation.
+// prim_order[i] = index into the BuildPrim array (post-build order) of the i-th primitive in leaf order.
+template <class R>
+int32_t collapse_to_wide(const std::vector<Bvh2Node> &n2, int root, std::vector<Node4<R>> &out,
+                         std::vector<int32_t> &prim_order, WideBvhStats &stats) {
+    out.clear();
+    prim_order.clear();
+    stats = WideBvhStats{};
+    if (root < 0) return CHILD_EMPTY;
+    auto emit_leaf = [&](const Bvh2Node &n) {
+        int32_t first = (int32_t)prim_order.size();
+        for (int i = 0; i < n.count; i++) prim_order.push_back(n.first + i);
+        return make_leaf(first, n.count);
+    };
+    if (n2[root].count > 0) {
+        stats.n_prims = n2[root].count;
+        stats.depth = 0;
+        return emit_leaf(n2[root]);
+    }
+    struct Item {
+        int n2;
+        int depth;
+    };
+    std::vector<Item> queue;
+    queue.push_back({root, 1});
+    out.emplace_back();
+    size_t head = 0;
+    while (head < queue.size()) {
+        const Item it = queue[head];
+        const size_t self = head++;
+        int kids[4];
+        int nk = 0;
+        kids[nk++] = n2[it.n2].left;
+        kids[nk++] = n2[it.n2].right;
+        while (nk < 4) {
+            int best = -1;
+            double best_area = -1;
+            for (int i = 0; i < nk; i++) {
+                const Bvh2Node &c = n2[kids[i]];
+                if (c.count > 0) continue;
+                Bounds b;
+                b.grow(c.bmin, c.bmax);
+                double a = b.half_area();
+                if (a > best_area) best_area = a, best = i;
+            }
+            if (best < 0) break;
+            const int open = kids[best];
+            kids[best] = n2[open].left;
+            kids[nk++] = n2[open].right;
+        }
+        Node4<R> node;
+        for (int i = 0; i < 4; i++) {
+            node.pad[i] = 0;
+            if (i < nk) {
+                const Bvh2Node &c = n2[kids[i]];
+                for (int a = 0; a < 3; a++) {
+                    node.bmin[a][i] = round_down(c.bmin[a], R());
+                    node.bmax[a][i] = round_up(c.bmax[a], R());
+                }
+                if (c.count > 0) {
+                    node.child[i] = emit_leaf(c);
+                } else {
+                    node.child[i] = (int32_t)queue.size();
+                    queue.push_back({kids[i], it.depth + 1});
+                    out.emplace_back();
+                }
+            } else {
+                for (int a = 0; a < 3; a++) node.bmin[a][i] = Const<R>::inf(), node.bmax[a][i] = -Const<R>::inf();
+                node.child[i] = CHILD_EMPTY;
+            }
+        }
+        out[self] = node;
+        stats.depth = std::max(stats.depth, it.depth);
+    }
+    stats.n_nodes = (int64_t)out.size();
+    stats.n_prims = (int64_t)prim_order.size();
+    return 0;  // root node index
+}
+
+}  // namespace tk

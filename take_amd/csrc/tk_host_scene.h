@@ -1,0 +1,255 @@
+// tk_host_scene.h — host-side preparation of a scene: validates a TakeSceneDesc, converts it to the
+// R-typed arrays of tk_scene.h, builds the wide BVH.  The result is a set of plain host vectors; the C-ABI
+// layer (tk_api.hip) uploads them to HBM.  Counterpart of the part of the reference's render() between
+// parse_scene and the tile loop (src/render.cpp:37-50) plus build_bvh (src/scene.cpp:4-23).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "take_hip.h"
+#include "tk_bvh.h"
+#include "tk_scene.h"
+
+namespace tk {
+
+template <class R> struct HostScene {
+    std::vector<Node4<R>> nodes;
+    std::vector<PrimRec<R>> prims;
+    int32_t root_child = CHILD_EMPTY;
+    std::vector<ShapeInfo> shapes;
+    std::vector<MeshInfo> meshes;
+    std::vector<int32_t> face_idx;
+    std::vector<R> normals, uvs, texels;
+    std::vector<MaterialRec<R>> materials;
+    std::vector<ImageInfo> images;
+    std::vector<LightRec<R>> lights;
+    R background[3];
+    CameraRec<R> cam;
+    WideBvhStats stats;
+    int n_material_tags = 0;  // distinct material tags in use (1 => the material sort is skipped)
+
+    // pointers into the vectors above (a host "device scene" for tests/hostsim; tk_api.hip builds the real one)
+    DeviceScene<R> view() const {
+        DeviceScene<R> d{};
+        d.nodes = nodes.data();
+        d.prims = prims.data();
+        d.root_child = root_child;
+        d.n_nodes = (int32_t)nodes.size();
+        d.shapes = shapes.data();
+        d.meshes = meshes.data();
+        d.face_idx = face_idx.data();
+        d.normals = normals.data();
+        d.uvs = uvs.data();
+        d.materials = materials.data();
+        d.images = images.data();
+        d.texels = texels.data();
+        d.lights = lights.data();
+        d.n_lights = (int32_t)lights.size();
+        d.n_shapes = (int32_t)shapes.size();
+        for (int a = 0; a < 3; a++) d.background[a] = background[a];
+        d.cam = cam;
+        return d;
+    }
+};
+
+// Camera basis of src/render.cpp:37-44, in R arithmetic.
+template <class R> inline void make_camera(const TakeCamera &c, CameraRec<R> &out) {
+    const R vfov = R(c.vfov);
+    const R theta = vfov / R(180) * Const<R>::PI;
+    const R h = tk_tan(theta / R(2));
+    out.viewport_height = R(2) * h;
+    out.viewport_width = out.viewport_height / R(c.height) * R(c.width);
+    Vec3<R> from{R(c.lookfrom[0]), R(c.lookfrom[1]), R(c.lookfrom[2])};
+    Vec3<R> at{R(c.lookat[0]), R(c.lookat[1]), R(c.lookat[2])};
+    Vec3<R> up{R(c.up[0]), R(c.up[1]), R(c.up[2])};
+    Vec3<R> w = normalize(from - at);
+    Vec3<R> u = normalize(cross(up, w));
+    Vec3<R> v = cross(w, u);
+    out.u[0] = u.x, out.u[1] = u.y, out.u[2] = u.z;
+    out.v[0] = v.x, out.v[1] = v.y, out.v[2] = v.z;
+    out.w[0] = w.x, out.w[1] = w.y, out.w[2] = w.z;
+    out.lookfrom[0] = from.x, out.lookfrom[1] = from.y, out.lookfrom[2] = from.z;
+    out.width = c.width;
+    out.height = c.height;
+}
+
+// returns "" on success, else an error message (-> TAKE_E_INVALID)
+template <class R>
+std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, HostScene<R> &hs) {
+    if (d.camera.width <= 0 || d.camera.height <= 0) return "camera width/height must be positive";
+    if (d.n_shapes < 0 || d.n_meshes < 0 || d.n_spheres < 0 || d.n_lights < 0 || d.n_materials < 0 || d.n_images < 0)
+        return "negative count in scene description";
+    if (d.n_shapes > 0 && (!d.shape_kind || !d.shape_ref || !d.shape_face || !d.shape_area_light))
+        return "shape arrays missing";
+    if (d.n_shapes >= (int64_t)1 << 28) return "too many shapes for the 4-wide leaf encoding (2^28)";
+    make_camera<R>(d.camera, hs.cam);
+    for (int a = 0; a < 3; a++) hs.background[a] = R(d.background[a]);
+
+    // meshes: concatenate face indices; normals / uvs only for meshes that carry them
+    hs.meshes.resize(d.n_meshes);
+    int64_t nf = 0, nn = 0, nuv = 0;
+    for (int i = 0; i < d.n_meshes; i++) {
+        const TakeMesh &m = d.meshes[i];
+        if (m.n_vertices < 0 || m.n_faces < 0 || (m.n_faces > 0 && (!m.positions || !m.indices)))
+            return "mesh " + std::to_string(i) + ": missing arrays";
+        if (m.material_id < 0 || m.material_id >= d.n_materials) return "mesh " + std::to_string(i) + ": bad material id";
+        hs.meshes[i] = MeshInfo{(int32_t)nf, m.normals ? (int32_t)nn : -1, m.uvs ? (int32_t)nuv : -1, m.material_id};
+        nf += m.n_faces;
+        if (m.normals) nn += m.n_vertices;
+        if (m.uvs) nuv += m.n_vertices;
+    }
+    if (nf >= (int64_t)1 << 30 || nn >= (int64_t)1 << 30 || nuv >= (int64_t)1 << 30) return "mesh arrays too large";
+    hs.face_idx.resize(3 * (size_t)nf);
+    hs.normals.resize(3 * (size_t)nn);
+    hs.uvs.resize(2 * (size_t)nuv);
+    for (int i = 0; i < d.n_meshes; i++) {
+        const TakeMesh &m = d.meshes[i];
+        const MeshInfo &mi = hs.meshes[i];
+        for (int64_t k = 0; k < 3 * m.n_faces; k++) {
+            const int32_t vi = m.indices[k];
+            if (vi < 0 || vi >= m.n_vertices) return "mesh " + std::to_string(i) + ": vertex index out of range";
+            hs.face_idx[3 * (size_t)mi.fbase + k] = vi;
+        }
+        if (m.normals)
+            for (int64_t k = 0; k < 3 * m.n_vertices; k++) hs.normals[3 * (size_t)mi.nbase + k] = R(m.normals[k]);
+        if (m.uvs)
+            for (int64_t k = 0; k < 2 * m.n_vertices; k++) hs.uvs[2 * (size_t)mi.uvbase + k] = R(m.uvs[k]);
+    }
+
+    // materials, textures
+    hs.materials.resize(d.n_materials);
+    bool tag_used[TAKE_MAT_COUNT] = {false};
+    for (int i = 0; i < d.n_materials; i++) {
+        const TakeMaterial &m = d.materials[i];
+        if (m.tag < 0 || m.tag >= TAKE_MAT_COUNT) return "material " + std::to_string(i) + ": unknown tag";
+        const TakeTexture &t = m.reflectance;
+        if (t.kind == 1 && (t.image_id < 0 || t.image_id >= d.n_images))
+            return "material " + std::to_string(i) + ": bad texture image id";
+        MaterialRec<R> &o = hs.materials[i];
+        o.tag = m.tag;
+        o.tex_kind = t.kind;
+        o.tex_image = t.image_id;
+        o.pad = 0;
+        for (int a = 0; a < 3; a++) o.color[a] = R(t.value[a]);
+        o.uscale = R(t.uscale), o.vscale = R(t.vscale), o.uoffset = R(t.uoffset), o.voffset = R(t.voffset);
+        o.p0 = R(m.param[0]);
+        o.p1 = R(m.param[1]);
+        tag_used[m.tag] = true;
+    }
+    hs.n_material_tags = 0;
+    for (bool b : tag_used) hs.n_material_tags += b ? 1 : 0;
+    hs.images.resize(d.n_images);
+    int64_t ntex = 0;
+    for (int i = 0; i < d.n_images; i++) {
+        if (d.images[i].width <= 0 || d.images[i].height <= 0 || !d.images[i].data) return "image: bad dimensions";
+        hs.images[i] = ImageInfo{d.images[i].width, d.images[i].height, ntex};
+        ntex += (int64_t)d.images[i].width * d.images[i].height;
+    }
+    hs.texels.resize(3 * (size_t)ntex);
+    for (int i = 0; i < d.n_images; i++) {
+        const int64_t n = (int64_t)d.images[i].width * d.images[i].height * 3;
+        for (int64_t k = 0; k < n; k++) hs.texels[3 * (size_t)hs.images[i].offset + k] = R(d.images[i].data[k]);
+    }
+
+    // shapes -> primitive records (shape order for now) + build boxes
+    const int64_t ns = d.n_shapes;
+    hs.shapes.resize(ns);
+    std::vector<PrimRec<R>> recs(ns);
+    std::vector<BuildPrim> bp(ns);
+    for (int64_t i = 0; i < ns; i++) {
+        PrimRec<R> &p = recs[i];
+        p = PrimRec<R>{};
+        p.shape_id = (int32_t)i;
+        const int32_t al = d.shape_area_light[i];
+        if (al < -1 || al >= d.n_lights) return "shape " + std::to_string(i) + ": bad area_light id";
+        int material;
+        if (d.shape_kind[i] == 0) {
+            const int32_t si = d.shape_ref[i];
+            if (si < 0 || si >= d.n_spheres) return "shape " + std::to_string(i) + ": bad sphere index";
+            const TakeSphere &s = d.spheres[si];
+            if (s.material_id < 0 || s.material_id >= d.n_materials) return "sphere: bad material id";
+            material = s.material_id;
+            for (int a = 0; a < 3; a++) p.a[a] = R(s.center[a]);
+            p.a[3] = R(s.radius);
+            hs.shapes[i] = ShapeInfo{-(1 + si), 0, material, al};
+            for (int a = 0; a < 3; a++) {  // bounds of src/scene.cpp:8-10, from the R-typed values
+                bp[i].bmin[a] = (double)(p.a[a] - p.a[3]);
+                bp[i].bmax[a] = (double)(p.a[a] + p.a[3]);
+                // an R-rounded centre-radius can round inwards by an ulp: widen in double
+                bp[i].bmin[a] = std::min(bp[i].bmin[a], (double)p.a[a] - (double)p.a[3]);
+                bp[i].bmax[a] = std::max(bp[i].bmax[a], (double)p.a[a] + (double)p.a[3]);
+            }
+            p.meta = PRIM_SPHERE;
+        } else if (d.shape_kind[i] == 1) {
+            const int32_t mi = d.shape_ref[i], fi = d.shape_face[i];
+            if (mi < 0 || mi >= d.n_meshes) return "shape " + std::to_string(i) + ": bad mesh index";
+            const TakeMesh &m = d.meshes[mi];
+            if (fi < 0 || fi >= m.n_faces) return "shape " + std::to_string(i) + ": bad face index";
+            material = m.material_id;
+            const int32_t *idx = m.indices + 3 * (int64_t)fi;
+            Vec3<R> v[3];
+            for (int k = 0; k < 3; k++)
+                v[k] = {R(m.positions[3 * (int64_t)idx[k]]), R(m.positions[3 * (int64_t)idx[k] + 1]),
+                        R(m.positions[3 * (int64_t)idx[k] + 2])};
+            const Vec3<R> e1 = v[1] - v[0], e2 = v[2] - v[0];
+            p.a[0] = v[0].x, p.a[1] = v[0].y, p.a[2] = v[0].z;
+            p.a[3] = e1.x, p.a[4] = e1.y, p.a[5] = e1.z;
+            p.a[6] = e2.x, p.a[7] = e2.y, p.a[8] = e2.z;
+            hs.shapes[i] = ShapeInfo{mi, fi, material, al};
+            for (int a = 0; a < 3; a++) {
+                const double x0 = (double)(&v[0].x)[a], x1 = (double)(&v[1].x)[a], x2 = (double)(&v[2].x)[a];
+                bp[i].bmin[a] = std::min(x0, std::min(x1, x2));
+                bp[i].bmax[a] = std::max(x0, std::max(x1, x2));
+            }
+            p.meta = PRIM_TRIANGLE;
+        } else {
+            return "shape " + std::to_string(i) + ": unknown kind";
+        }
+        p.meta |= hs.materials[material].tag << 8;
+        bp[i].id = (int32_t)i;
+    }
+
+    // lights
+    hs.lights.resize(d.n_lights);
+    for (int i = 0; i < d.n_lights; i++) {
+        const TakeLight &l = d.lights[i];
+        LightRec<R> &o = hs.lights[i];
+        o = LightRec<R>{};
+        o.kind = l.kind;
+        o.shape_id = -1;
+        for (int a = 0; a < 3; a++) o.intensity[a] = R(l.intensity[a]);
+        if (l.kind == 0) continue;
+        if (l.kind != 1) return "light " + std::to_string(i) + ": unknown kind";
+        if (l.shape_id < 0 || l.shape_id >= ns) return "light " + std::to_string(i) + ": bad shape id";
+        o.shape_id = l.shape_id;
+        const ShapeInfo &si = hs.shapes[l.shape_id];
+        if (si.mesh < 0) {
+            o.is_sphere = 1;
+            for (int a = 0; a < 4; a++) o.v[a] = recs[l.shape_id].a[a];
+        } else {
+            const TakeMesh &m = d.meshes[si.mesh];
+            // the reference reads mesh.normals.at() when sampling a triangle light and throws on an emissive
+            // mesh without vertex normals (src/shape.cpp:163-165): reject it up front
+            if (!m.normals) return "light " + std::to_string(i) + ": emissive mesh has no vertex normals";
+            const int32_t *idx = m.indices + 3 * (int64_t)si.face;
+            for (int k = 0; k < 3; k++)
+                for (int a = 0; a < 3; a++) {
+                    o.v[3 * k + a] = R(m.positions[3 * (int64_t)idx[k] + a]);
+                    o.n[3 * k + a] = R(m.normals[3 * (int64_t)idx[k] + a]);
+                }
+        }
+    }
+
+    // acceleration structure
+    Bvh2Builder builder(bp, max_leaf > 0 ? max_leaf : MAX_LEAF, threads);
+    const int root = builder.build();
+    std::vector<int32_t> order;
+    hs.root_child = collapse_to_wide<R>(builder.nodes(), root, hs.nodes, order, hs.stats);
+    hs.prims.resize(order.size());
+    for (size_t k = 0; k < order.size(); k++) hs.prims[k] = recs[bp[order[k]].id];
+    if (3 * hs.stats.depth + 1 > 96) return "BVH too deep for the traversal stack";
+    return "";
+}
+
+}  // namespace tk

@@ -1,0 +1,209 @@
+// tk_integrate.h — the integrator as per-path step functions of the wavefront pipeline.
+//
+// The reference's path_tracing() (src/integrator/path_tracing.h:5-111) is one loop per camera ray:
+//     primary hit; for i in 0..max_depth { NEE (shadow ray) ; BSDF sample ; extend ray ; MIS bookkeeping }
+// Here every path of a batch advances one loop iteration per launch round:
+//     generate -> [ trace_closest -> shade(k) -> trace_shadow ]  for k = 0 .. max_depth+1 -> accumulate
+// shade(k) finishes iteration k-1 with the hit the extend ray found (emitter MIS term C2, throughput update)
+// and starts iteration k (NEE sample -> shadow-ray request, BSDF sample -> extend-ray request).  The shadow
+// kernel adds throughput*C1 to the path's radiance when unoccluded; stream order puts that add before the next
+// shade's C2 add, which is the reference's order of additions.  All per-sample arithmetic, the order of random
+// draws and every `break` of the reference loop are kept; what changes is who executes them and when.
+#pragma once
+
+#include "tk_shade.h"
+
+namespace tk {
+
+template <class R> struct RenderParams {
+    int32_t width, height;
+    int32_t n_local_rows;   // rows this rank renders
+    int32_t npix;           // n_local_rows * width
+    int32_t strip_first, strip_stride;
+    int32_t spp;            // total samples per pixel
+    int32_t s0;             // first sample index of this batch
+    int32_t spb;            // samples per pixel in this batch
+    int32_t max_depth;
+    uint64_t seed;
+    R ray_eps;
+};
+
+constexpr int TILE_ROWS = 16;  // the reference's tile_size (src/render.cpp:52): strips are whole tile rows
+
+// local row -> render-loop y (y = 0 is the bottom image row: the reference stores img(x, height - y - 1))
+template <class R> TK_HD int local_row_to_y(const RenderParams<R> &rp, int lr) {
+    return (rp.strip_first + (lr / TILE_ROWS) * rp.strip_stride) * TILE_ROWS + (lr % TILE_ROWS);
+}
+
+template <class R> TK_HD Rng path_rng(const RenderParams<R> &rp, int64_t slot, uint32_t ctr) {
+    const int p = (int)(slot % rp.npix);
+    const int sl = (int)(slot / rp.npix);
+    const int lr = p / rp.width, x = p % rp.width;
+    const int y = local_row_to_y(rp, lr);
+    Rng r;
+    r.key = rng_key(rp.seed, (uint64_t)y * (uint64_t)rp.width + (uint64_t)x, (uint64_t)(rp.s0 + sl));
+    r.ctr = ctr;
+    return r;
+}
+
+// Camera ray of src/render.cpp:69-75.  The two jitters are drawn y first (the g++ evaluation order the golden
+// vectors pin).
+template <class R>
+TK_HD void generate_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, const PathState<R> &st, int64_t slot) {
+    const int p = (int)(slot % rp.npix);
+    const int lr = p / rp.width, x = p % rp.width;
+    const int y = local_row_to_y(rp, lr);
+    Rng rng = path_rng(rp, slot, 0);
+    const R ry = random_real<R>(rng);
+    const R rx = random_real<R>(rng);
+    const CameraRec<R> &c = sc.cam;
+    Vec3<R> d = normalize(ld3(c.u) * ((R(x) + rx) / R(c.width) - R(0.5)) * c.viewport_width +
+                          ld3(c.v) * ((R(y) + ry) / R(c.height) - R(0.5)) * c.viewport_height - ld3(c.w));
+    st.R_(S_OX, slot) = c.lookfrom[0];
+    st.R_(S_OY, slot) = c.lookfrom[1];
+    st.R_(S_OZ, slot) = c.lookfrom[2];
+    st.R_(S_DX, slot) = d.x;
+    st.R_(S_DY, slot) = d.y;
+    st.R_(S_DZ, slot) = d.z;
+    st.R_(S_TX, slot) = R(1);
+    st.R_(S_TY, slot) = R(1);
+    st.R_(S_TZ, slot) = R(1);
+    st.R_(S_LX, slot) = R(0);
+    st.R_(S_LY, slot) = R(0);
+    st.R_(S_LZ, slot) = R(0);
+    st.I_(S_CTR, slot) = (int32_t)rng.ctr;
+    st.I_(S_FLAGS, slot) = 0;
+}
+
+constexpr uint32_t REQ_EXTEND = 1, REQ_SHADOW = 2;
+
+// One launch round for one path.  `k` is the shade round (uniform over the launch): k = 0 handles the camera
+// ray's hit, k >= 1 finishes loop iteration k-1; iteration k is started when k <= max_depth.
+// Returns REQ_* bits: which rays this path wants traced next.
+template <class R>
+TK_HD uint32_t shade_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, const PathState<R> &st, int64_t slot,
+                          int k) {
+    const int32_t hit_prim = st.I_(S_HIT, slot);
+    const Vec3<R> ro{st.R_(S_OX, slot), st.R_(S_OY, slot), st.R_(S_OZ, slot)};
+    const Vec3<R> rd{st.R_(S_DX, slot), st.R_(S_DY, slot), st.R_(S_DZ, slot)};
+    Vec3<R> thr{st.R_(S_TX, slot), st.R_(S_TY, slot), st.R_(S_TZ, slot)};
+    Vec3<R> rad{st.R_(S_LX, slot), st.R_(S_LY, slot), st.R_(S_LZ, slot)};
+    const Vec3<R> bg = ld3(sc.background);
+    const R nlights = R(sc.n_lights);
+    Isect<R> v;
+    bool alive = true;
+
+    if (k == 0) {
+        // src/integrator/path_tracing.h:7-18
+        if (hit_prim < 0) {
+            rad = bg;
+            alive = false;
+        } else {
+            make_isect(sc, ro, rd, hit_prim, st.R_(S_HT, slot), st.R_(S_HU, slot), st.R_(S_HV, slot), v);
+            if (v.area_light != -1) {
+                const LightRec<R> &l = sc.lights[v.area_light];
+                if (l.kind == 1) rad = rad + thr * ld3(l.intensity);
+            }
+        }
+    } else {
+        // second half of loop iteration k-1: src/integrator/path_tracing.h:82-108
+        const Vec3<R> FG{st.R_(S_FX, slot), st.R_(S_FY, slot), st.R_(S_FZ, slot)};
+        const R pdf = st.R_(S_PDF, slot);
+        const bool was_specular = (st.I_(S_FLAGS, slot) & FLAG_SPECULAR) != 0;
+        if (hit_prim < 0) {
+            thr = thr * (FG / pdf);
+            rad = rad + thr * bg;
+            alive = false;
+        } else {
+            make_isect(sc, ro, rd, hit_prim, st.R_(S_HT, slot), st.R_(S_HU, slot), st.R_(S_HV, slot), v);
+            Vec3<R> C2{R(0), R(0), R(0)};
+            if (v.area_light != -1) {
+                const LightRec<R> &l = sc.lights[v.area_light];
+                const R d = length(v.pos - ro);
+                const Vec3<R> light_dir = normalize(v.pos - ro);
+                const R light_pdf =
+                    light_pdf_area(l, v.pos, ro) * (d * d) / (tk_fmax(dot(-v.gn, light_dir), R(0)) * nlights);
+                if (light_pdf <= R(0)) {
+                    alive = false;  // `break` at :93-96 — before the C2 add and the throughput update
+                } else if (l.kind == 1) {
+                    C2 = FG * ld3(l.intensity) *
+                         (was_specular ? (R(1) / pdf) : (pdf / (light_pdf * light_pdf + pdf * pdf)));
+                }
+            }
+            if (alive) {
+                rad = rad + thr * C2;
+                thr = thr * (FG / pdf);
+            }
+        }
+    }
+
+    uint32_t req = 0;
+    if (alive && k <= rp.max_depth) {
+        // first half of loop iteration k: src/integrator/path_tracing.h:22-81
+        Rng rng = path_rng(rp, slot, (uint32_t)st.I_(S_CTR, slot));
+        const Vec3<R> dir_in = -rd;
+        const MaterialRec<R> &m = sc.materials[v.material];
+        const bool is_specular = (m.tag == 2 || m.tag == 1);
+        if (sc.n_lights > 0 && !is_specular) {
+            const int light_id = (int)tk_floor(random_real<R>(rng) * nlights);
+            const LightRec<R> &l = sc.lights[light_id];
+            if (l.kind == 1) {
+                const LightSample<R> lp = sample_light_point(l, v.pos, rng);
+                const R d = length(lp.pos - v.pos);
+                const Vec3<R> light_dir = normalize(lp.pos - v.pos);
+                const R light_pdf =
+                    light_pdf_area(l, lp.pos, v.pos) * (d * d) / (tk_fmax(dot(-lp.n, light_dir), R(0)) * nlights);
+                if (light_pdf <= R(0)) {
+                    alive = false;  // `break` at :40-43
+                } else {
+                    const R bp = bsdf_pdf(m, dir_in, light_dir, v);
+                    if (bp > R(0) && !tk_isinf(light_pdf)) {
+                        const Vec3<R> FGl = eval_bsdf(sc, m, dir_in, light_dir, R(0), v);
+                        const Vec3<R> C1 = FGl * ld3(l.intensity) * light_pdf / (light_pdf * light_pdf + bp * bp);
+                        const Vec3<R> add = thr * C1;
+                        st.R_(S_SX, slot) = light_dir.x;
+                        st.R_(S_SY, slot) = light_dir.y;
+                        st.R_(S_SZ, slot) = light_dir.z;
+                        st.R_(S_ST, slot) = (R(1) - rp.ray_eps) * d;
+                        st.R_(S_CX, slot) = add.x;
+                        st.R_(S_CY, slot) = add.y;
+                        st.R_(S_CZ, slot) = add.z;
+                        req |= REQ_SHADOW;
+                    }
+                }
+            }
+        }
+        if (alive) {
+            BsdfSample<R> rec;
+            if (sample_bsdf(m, dir_in, v, rng, rec)) {
+                const Vec3<R> FG = eval_bsdf(sc, m, dir_in, rec.dir_out, rec.pdf, v);
+                const Vec3<R> dir_out = normalize(rec.dir_out);
+                if (rec.pdf > R(0)) {
+                    st.R_(S_DX, slot) = dir_out.x;
+                    st.R_(S_DY, slot) = dir_out.y;
+                    st.R_(S_DZ, slot) = dir_out.z;
+                    st.R_(S_FX, slot) = FG.x;
+                    st.R_(S_FY, slot) = FG.y;
+                    st.R_(S_FZ, slot) = FG.z;
+                    st.R_(S_PDF, slot) = rec.pdf;
+                    st.I_(S_FLAGS, slot) = is_specular ? FLAG_SPECULAR : 0;
+                    req |= REQ_EXTEND;
+                }
+            }
+        }
+        // both rays of this iteration start at the vertex
+        st.R_(S_OX, slot) = v.pos.x;
+        st.R_(S_OY, slot) = v.pos.y;
+        st.R_(S_OZ, slot) = v.pos.z;
+        st.I_(S_CTR, slot) = (int32_t)rng.ctr;
+    }
+    st.R_(S_TX, slot) = thr.x;
+    st.R_(S_TY, slot) = thr.y;
+    st.R_(S_TZ, slot) = thr.z;
+    st.R_(S_LX, slot) = rad.x;
+    st.R_(S_LY, slot) = rad.y;
+    st.R_(S_LZ, slot) = rad.z;
+    return req;
+}
+
+}  // namespace tk

@@ -1,0 +1,307 @@
+// tk_kernels.h — the HIP kernels of the wavefront path tracer (gfx950, wave64).
+//
+//   k_generate        camera rays for one batch (src/render.cpp:69-75)
+//   k_trace<false>    closest hit for the extend queue      (scene_intersect,  src/scene.cpp:25)
+//   k_trace<true>     first hit for the shadow queue        (scene_occluded,   src/scene.cpp:49) + radiance add
+//   k_shade           one integrator round per path + wave-aggregated compaction into the next queues
+//   k_sort_*          counting sort of the extend queue by the material tag of the hit
+//   k_accumulate      per-pixel sum of the batch's samples, in sample order (src/render.cpp:68-77)
+//   k_resolve         divide by spp, vertical flip (src/render.cpp:78)
+//   k_trace_rays      the C-ABI trace hooks: AoS rays in, hit records out
+//
+// Launch shape: the trace kernels are persistent (grid = CUs x resident blocks); each wave pulls 64-ray chunks
+// from a device-side head counter, so a round needs no host read-back of the queue length and expensive rays do
+// not stall a fixed partition.  Traversal stacks live in LDS ([level][thread] int2, conflict-free
+// ds_write_b64/ds_read_b64), with a global spill area behind level LDS_STACK.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "tk_integrate.h"
+
+namespace tk {
+
+constexpr int BLOCK = 256;        // 4 waves
+constexpr int LDS_STACK = 16;     // stack levels kept in LDS per lane (8 B each -> 32 KB per block)
+constexpr int SPILL_STACK = 80;   // deeper levels: global memory, per persistent thread
+constexpr int WAVE = 64;
+
+struct StackSpill {
+    int2 *base;  // SPILL_STACK entries per thread of the persistent grid, [level][global thread]
+    int64_t stride;
+};
+
+struct LdsStack {
+    int2 *lds;      // &shared[threadIdx.x], level stride BLOCK
+    int2 *spill;    // &spill.base[global thread], level stride spill_stride
+    int64_t spill_stride;
+    __device__ __forceinline__ void push(int level, int32_t child, float key) {
+        int2 e = make_int2(child, __float_as_int(key));
+        if (level < LDS_STACK)
+            lds[level * BLOCK] = e;
+        else
+            spill[(int64_t)(level - LDS_STACK) * spill_stride] = e;
+    }
+    __device__ __forceinline__ void pop(int level, int32_t &child, float &key) {
+        int2 e = (level < LDS_STACK) ? lds[level * BLOCK] : spill[(int64_t)(level - LDS_STACK) * spill_stride];
+        child = e.x;
+        key = __int_as_float(e.y);
+    }
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+// rank of this lane among the set bits of `mask` below it
+__device__ __forceinline__ int mask_rank(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+// Wave-aggregated append: every lane of the wave calls it (convergent); lanes with `want` get a slot.
+__device__ __forceinline__ void wave_append(bool want, int32_t value, int32_t *counter, int32_t *queue) {
+    const uint64_t mask = __ballot(want);
+    if (mask == 0) return;
+    const int leader = __ffsll((unsigned long long)mask) - 1;
+    int32_t base = 0;
+    if (lane_id() == leader) base = atomicAdd(counter, (int32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (want) queue[base + mask_rank(mask)] = value;
+}
+
+template <class R>
+__global__ void __launch_bounds__(BLOCK)
+k_generate(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, int32_t *queue, int64_t n) {
+    for (int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x; s < n; s += (int64_t)gridDim.x * BLOCK) {
+        generate_path(sc, rp, st, s);
+        queue[s] = (int32_t)s;
+    }
+}
+
+// Persistent trace kernel.  SHADOW=false: closest hit, writes the hit record.  SHADOW=true: first hit along the
+// shadow segment; an unoccluded path adds its pending throughput*C1 to its radiance (path_tracing.h:53-58).
+template <class R, bool SHADOW, bool COUNT>
+__global__ void __launch_bounds__(BLOCK)
+k_trace(DeviceScene<R> sc, PathState<R> st, const int32_t *__restrict__ queue, const int32_t *__restrict__ n_ptr,
+        int32_t *head, R ray_eps, unsigned long long *counters, StackSpill spill) {
+    __shared__ int2 s_stack[LDS_STACK * BLOCK];
+    LdsStack stack;
+    stack.lds = &s_stack[threadIdx.x];
+    stack.spill = spill.base + ((int64_t)blockIdx.x * BLOCK + threadIdx.x);
+    stack.spill_stride = spill.stride;
+    const int32_t n = *n_ptr;
+    TravCount tc;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        atomicAdd(&counters[SHADOW ? C_RAYS_SHADOW : C_RAYS_CLOSEST], (unsigned long long)n);
+    for (;;) {
+        int32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(head, WAVE);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) break;
+        const int32_t i = base + lane_id();
+        if (i < n) {
+            const int64_t slot = queue[i];
+            HitT<R> hit;
+            if (!SHADOW) {
+                RayT<R> ray = make_ray(st.R_(S_OX, slot), st.R_(S_OY, slot), st.R_(S_OZ, slot), st.R_(S_DX, slot),
+                                       st.R_(S_DY, slot), st.R_(S_DZ, slot), ray_eps, Const<R>::inf());
+                traverse<R, false, COUNT>(sc, ray, stack, hit, tc);
+                st.I_(S_HIT, slot) = hit.prim;
+                st.R_(S_HT, slot) = hit.t;
+                st.R_(S_HU, slot) = hit.u;
+                st.R_(S_HV, slot) = hit.v;
+            } else {
+                RayT<R> ray = make_ray(st.R_(S_OX, slot), st.R_(S_OY, slot), st.R_(S_OZ, slot), st.R_(S_SX, slot),
+                                       st.R_(S_SY, slot), st.R_(S_SZ, slot), ray_eps, st.R_(S_ST, slot));
+                traverse<R, true, COUNT>(sc, ray, stack, hit, tc);
+                if (hit.prim < 0) {
+                    st.R_(S_LX, slot) = st.R_(S_LX, slot) + st.R_(S_CX, slot);
+                    st.R_(S_LY, slot) = st.R_(S_LY, slot) + st.R_(S_CY, slot);
+                    st.R_(S_LZ, slot) = st.R_(S_LZ, slot) + st.R_(S_CZ, slot);
+                }
+            }
+        }
+    }
+    if (COUNT) {
+        // wave-level reduction, one atomic per wave
+        unsigned long long nn = tc.nodes, pp = tc.prims;
+        for (int off = 32; off > 0; off >>= 1) {
+            nn += __shfl_down(nn, off);
+            pp += __shfl_down(pp, off);
+        }
+        if (lane_id() == 0) {
+            atomicAdd(&counters[C_NODE_VISITS], nn);
+            atomicAdd(&counters[C_PRIM_TESTS], pp);
+        }
+    }
+}
+
+// One integrator round.  Requests are compacted into the next extend queue and the shadow queue with one
+// atomic per wave and queue (ballot + mbcnt prefix).
+template <class R>
+__global__ void __launch_bounds__(BLOCK)
+k_shade(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, const int32_t *__restrict__ queue,
+        const int32_t *__restrict__ n_ptr, int32_t *next_queue, int32_t *n_next, int32_t *shadow_queue,
+        int32_t *n_shadow, int k, unsigned long long *counters) {
+    const int32_t n = *n_ptr;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[C_BOUNCES], (unsigned long long)n);
+    const int32_t n_round = (n + WAVE - 1) / WAVE * WAVE;
+    for (int32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += gridDim.x * BLOCK) {
+        uint32_t req = 0;
+        int32_t slot = 0;
+        if (i < n) {
+            slot = queue[i];
+            req = shade_path(sc, rp, st, (int64_t)slot, k);
+        }
+        wave_append((req & REQ_EXTEND) != 0, slot, n_next, next_queue);
+        wave_append((req & REQ_SHADOW) != 0, slot, n_shadow, shadow_queue);
+    }
+}
+
+// ---- material sort of the extend queue (after trace_closest, before shade): counting sort on the tag of the
+// hit primitive (PrimRec::meta >> 8; misses sort last).  tag_count/tag_cursor: TAKE_MAT_COUNT + 1 words each.
+constexpr int N_SORT_KEYS = 13;
+template <class R> __device__ __forceinline__ int sort_key(const DeviceScene<R> &sc, const PathState<R> &st, int32_t slot) {
+    const int32_t prim = st.I_(S_HIT, slot);
+    return prim < 0 ? N_SORT_KEYS - 1 : ((sc.prims[prim].meta >> 8) & 0xff);
+}
+template <class R>
+__global__ void __launch_bounds__(BLOCK)
+k_sort_count(DeviceScene<R> sc, PathState<R> st, const int32_t *__restrict__ queue, const int32_t *__restrict__ n_ptr,
+             int32_t *tag_count) {
+    __shared__ int32_t s_cnt[N_SORT_KEYS];
+    if (threadIdx.x < N_SORT_KEYS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int32_t n = *n_ptr;
+    for (int32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+        atomicAdd(&s_cnt[sort_key(sc, st, queue[i])], 1);
+    __syncthreads();
+    if (threadIdx.x < N_SORT_KEYS && s_cnt[threadIdx.x]) atomicAdd(&tag_count[threadIdx.x], s_cnt[threadIdx.x]);
+}
+template <class R>
+__global__ void __launch_bounds__(BLOCK)
+k_sort_scatter(DeviceScene<R> sc, PathState<R> st, const int32_t *__restrict__ queue,
+               const int32_t *__restrict__ n_ptr, const int32_t *__restrict__ tag_count, int32_t *tag_cursor,
+               int32_t *sorted) {
+    const int32_t n = *n_ptr;
+    int32_t basek[N_SORT_KEYS];
+    int32_t acc = 0;
+#pragma unroll
+    for (int t = 0; t < N_SORT_KEYS; t++) {
+        basek[t] = acc;
+        acc += tag_count[t];
+    }
+    const int32_t n_round = (n + WAVE - 1) / WAVE * WAVE;
+    for (int32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += gridDim.x * BLOCK) {
+        const bool valid = i < n;
+        const int32_t slot = valid ? queue[i] : 0;
+        const int key = valid ? sort_key(sc, st, slot) : -1;
+        // one aggregated append per tag present in the wave
+        uint64_t todo = __ballot(valid);
+        while (todo) {
+            const int leader = __ffsll((unsigned long long)todo) - 1;
+            const int kk = __shfl(key, leader);
+            const bool mine = valid && key == kk;
+            const uint64_t m = __ballot(mine);
+            int32_t base = 0;
+            if (lane_id() == leader) base = atomicAdd(&tag_cursor[kk], (int32_t)__popcll(m));
+            base = __shfl(base, leader);
+            if (mine) {
+                int32_t b = 0;
+#pragma unroll
+                for (int t = 0; t < N_SORT_KEYS; t++) b = (t == kk) ? basek[t] : b;
+                sorted[b + base + mask_rank(m)] = slot;
+            }
+            todo &= ~m;
+        }
+    }
+}
+
+// src/render.cpp:68-77: color += sample, in sample order.
+template <class R>
+__global__ void __launch_bounds__(BLOCK)
+k_accumulate(PathState<R> st, R *accum, int32_t npix, int32_t spb) {
+    for (int32_t p = blockIdx.x * BLOCK + threadIdx.x; p < npix; p += gridDim.x * BLOCK) {
+        R r = accum[3 * (int64_t)p], g = accum[3 * (int64_t)p + 1], b = accum[3 * (int64_t)p + 2];
+        for (int s = 0; s < spb; s++) {
+            const int64_t slot = (int64_t)s * npix + p;
+            r = r + st.R_(S_LX, slot);
+            g = g + st.R_(S_LY, slot);
+            b = b + st.R_(S_LZ, slot);
+        }
+        accum[3 * (int64_t)p] = r;
+        accum[3 * (int64_t)p + 1] = g;
+        accum[3 * (int64_t)p + 2] = b;
+    }
+}
+// src/render.cpp:78: img(x, height - y - 1) = color / spp — the local rows come out in increasing image row.
+template <class R>
+__global__ void __launch_bounds__(BLOCK)
+k_resolve(const R *__restrict__ accum, R *out, int32_t width, int32_t n_local_rows, int32_t spp) {
+    const int32_t npix = width * n_local_rows;
+    const R inv = R(1) / R(spp);
+    for (int32_t p = blockIdx.x * BLOCK + threadIdx.x; p < npix; p += gridDim.x * BLOCK) {
+        const int lr = p / width, x = p % width;
+        const int64_t o = 3 * ((int64_t)(n_local_rows - 1 - lr) * width + x);
+        out[o] = accum[3 * (int64_t)p] * inv;
+        out[o + 1] = accum[3 * (int64_t)p + 1] * inv;
+        out[o + 2] = accum[3 * (int64_t)p + 2] * inv;
+    }
+}
+
+// ---- C-ABI trace hooks: rays as TakeRayF/TakeRayD (8 Reals), hits as TakeHitF / TakeHitD
+template <class R> struct RayAoS {
+    R org[3], tmin, dir[3], tmax;
+};
+template <class R> struct HitAoS;
+template <> struct HitAoS<float> {
+    int32_t shape_id;
+    float t, u, v;
+};
+template <> struct HitAoS<double> {
+    int32_t shape_id, reserved;
+    double t, u, v;
+};
+template <class R, bool ANY, bool COUNT>
+__global__ void __launch_bounds__(BLOCK)
+k_trace_rays(DeviceScene<R> sc, const RayAoS<R> *__restrict__ rays, int64_t n, HitAoS<R> *hits, int32_t *occluded,
+             int32_t *head, unsigned long long *counters, StackSpill spill) {
+    __shared__ int2 s_stack[LDS_STACK * BLOCK];
+    LdsStack stack;
+    stack.lds = &s_stack[threadIdx.x];
+    stack.spill = spill.base + ((int64_t)blockIdx.x * BLOCK + threadIdx.x);
+    stack.spill_stride = spill.stride;
+    TravCount tc;
+    for (;;) {
+        int32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(head, WAVE);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) break;
+        const int64_t i = (int64_t)base + lane_id();
+        if (i < n) {
+            const RayAoS<R> q = rays[i];
+            RayT<R> ray = make_ray(q.org[0], q.org[1], q.org[2], q.dir[0], q.dir[1], q.dir[2], q.tmin, q.tmax);
+            HitT<R> hit;
+            traverse<R, ANY, COUNT>(sc, ray, stack, hit, tc);
+            if (ANY) {
+                occluded[i] = hit.prim >= 0 ? 1 : 0;
+            } else {
+                HitAoS<R> h{};
+                h.shape_id = hit.shape;
+                h.t = hit.prim >= 0 ? hit.t : R(0);
+                h.u = hit.u;
+                h.v = hit.v;
+                hits[i] = h;
+            }
+        }
+    }
+    if (COUNT) {
+        unsigned long long nn = tc.nodes, pp = tc.prims;
+        for (int off = 32; off > 0; off >>= 1) {
+            nn += __shfl_down(nn, off);
+            pp += __shfl_down(pp, off);
+        }
+        if (lane_id() == 0) {
+            atomicAdd(&counters[C_NODE_VISITS], nn);
+            atomicAdd(&counters[C_PRIM_TESTS], pp);
+        }
+    }
+}
+
+}  // namespace tk

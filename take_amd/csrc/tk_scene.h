@@ -1,0 +1,146 @@
+// tk_scene.h — device-side scene layout (what lives in HBM) and the path-state SoA.
+//
+// Layout rules (DESIGN.md §HBM layout):
+//  * BVH: 4-wide nodes, one 128-byte record per node in f32 (one L2 line): child boxes SoA inside the
+//    node (bmin[axis][4], bmax[axis][4]) + 4 child words.  Nodes are in breadth-first order, so the top
+//    levels are a prefix of the array.
+//  * Primitives are stored in leaf order as pre-transformed records (v0, e1, e2 | centre, radius) so a
+//    leaf is one contiguous run; 48 B in f32.
+//  * Everything the shading stage needs (vertex normals, uvs, materials, lights, texels) is indexed by the
+//    shape id a hit returns; it is touched once per bounce, not per node.
+//  * Path state is SoA with component stride = slots in flight: lane i of a wave touches element i of
+//    each component array -> coalesced.
+#pragma once
+
+#include "tk_common.h"
+
+namespace tk {
+
+constexpr int32_t CHILD_EMPTY = (int32_t)0x80000000;
+constexpr int MAX_LEAF = 4;
+
+// child word: >= 0 interior node index; < 0 (and != CHILD_EMPTY) leaf: -(1 + first*4 + (count-1))
+TK_HD int32_t make_leaf(int32_t first, int32_t count) { return -(1 + first * MAX_LEAF + (count - 1)); }
+TK_HD int32_t leaf_first(int32_t c) { return (-c - 1) / MAX_LEAF; }
+TK_HD int32_t leaf_count(int32_t c) { return ((-c - 1) % MAX_LEAF) + 1; }
+
+template <class R> struct alignas(16) Node4 {
+    R bmin[3][4];
+    R bmax[3][4];
+    int32_t child[4];
+    int32_t pad[4];  // f32: 96 + 16 + 16 = 128 B
+};
+static_assert(sizeof(Node4<float>) == 128, "one L2 line per f32 node");
+
+constexpr int32_t PRIM_TRIANGLE = 0;
+constexpr int32_t PRIM_SPHERE = 1;
+// triangle: a = v0.xyz, e1.xyz, e2.xyz (e = v_k - v0 in R arithmetic, as the reference computes per test,
+// src/shape.cpp:52-53); sphere: a[0..2] = centre, a[3] = radius.  meta = kind | material tag << 8.
+template <class R> struct alignas(16) PrimRec {
+    R a[9];
+    int32_t shape_id;
+    int32_t meta;
+    int32_t pad[sizeof(R) == 4 ? 1 : 2];
+};
+static_assert(sizeof(PrimRec<float>) == 48, "48-byte f32 primitive record");
+static_assert(sizeof(PrimRec<double>) == 96 || sizeof(PrimRec<double>) == 88 || sizeof(PrimRec<double>) == 80,
+              "f64 primitive record");
+
+struct ShapeInfo {  // indexed by shape id
+    int32_t mesh;   // >= 0 mesh id (triangle); < 0: a sphere (-(1 + sphere id))
+    int32_t face;   // face id within the mesh
+    int32_t material;
+    int32_t area_light;
+};
+struct MeshInfo {
+    int32_t fbase;   // first face of this mesh in face_idx (units: faces)
+    int32_t nbase;   // first vertex normal (units: vertices), -1 if the mesh has none
+    int32_t uvbase;  // first uv, -1 if none
+    int32_t material;
+};
+template <class R> struct MaterialRec {
+    int32_t tag, tex_kind, tex_image, pad;
+    R color[3];
+    R uscale, vscale, uoffset, voffset;
+    R p0, p1;
+};
+struct ImageInfo {
+    int32_t width, height;
+    int64_t offset;  // first texel (units: texels) in `texels`
+};
+template <class R> struct LightRec {
+    int32_t kind;      // 0 point, 1 diffuse area
+    int32_t shape_id;  // -1 for point lights
+    int32_t is_sphere;
+    int32_t pad;
+    R intensity[3];
+    R v[9];  // triangle: v0 v1 v2 | sphere: centre, radius
+    R n[9];  // triangle: vertex normals n0 n1 n2
+};
+
+template <class R> struct CameraRec {
+    R u[3], v[3], w[3], lookfrom[3];
+    R viewport_width, viewport_height;
+    int32_t width, height;
+};
+
+// All device pointers of one scene.  Passed to kernels by value.
+template <class R> struct DeviceScene {
+    const Node4<R> *nodes;
+    const PrimRec<R> *prims;
+    int32_t root_child;  // child word of the root (a leaf word when the scene has <= MAX_LEAF shapes)
+    int32_t n_nodes;
+    const ShapeInfo *shapes;
+    const MeshInfo *meshes;
+    const int32_t *face_idx;  // 3 local vertex ids per face, all meshes concatenated
+    const R *normals;         // 3 per vertex, meshes with normals concatenated
+    const R *uvs;             // 2 per vertex, meshes with uvs concatenated
+    const MaterialRec<R> *materials;
+    const ImageInfo *images;
+    const R *texels;  // 3 per texel
+    const LightRec<R> *lights;
+    int32_t n_lights;
+    int32_t n_shapes;
+    R background[3];
+    CameraRec<R> cam;
+};
+
+// ---- path state: component c of slot s lives at base[c * stride + s]
+enum StateR {
+    S_OX, S_OY, S_OZ,   // ray origin = position of the current vertex
+    S_DX, S_DY, S_DZ,   // ray direction (extend ray)
+    S_TX, S_TY, S_TZ,   // throughput
+    S_LX, S_LY, S_LZ,   // radiance of this sample so far
+    S_FX, S_FY, S_FZ,   // FG of the pending BSDF sample
+    S_PDF,              // its pdf
+    S_HT, S_HU, S_HV,   // closest-hit record of the extend ray
+    S_SX, S_SY, S_SZ,   // shadow-ray direction
+    S_ST,               // shadow-ray tmax
+    S_CX, S_CY, S_CZ,   // throughput * C1: added to radiance if the shadow ray is unoccluded
+    S_NUM_R
+};
+enum StateI { S_HIT, S_CTR, S_FLAGS, S_NUM_I };
+constexpr int32_t FLAG_SPECULAR = 1;
+
+template <class R> struct PathState {
+    R *r;        // S_NUM_R * stride
+    int32_t *i;  // S_NUM_I * stride
+    int64_t stride;
+    TK_HD R &R_(int c, int64_t s) const { return r[(int64_t)c * stride + s]; }
+    TK_HD int32_t &I_(int c, int64_t s) const { return i[(int64_t)c * stride + s]; }
+};
+
+// queue bookkeeping words (one small device array)
+enum QueueWord {
+    Q_N_EXT0, Q_N_EXT1,   // sizes of the two extend queues (ping-pong)
+    Q_N_SHADOW,           // size of the shadow queue
+    Q_HEAD_CLOSEST,       // work-fetch head of the closest-hit kernel
+    Q_HEAD_SHADOW,        // work-fetch head of the shadow kernel
+    Q_HEAD_SHADE,
+    Q_NUM_WORDS = 16
+};
+
+// instrumentation counters (device, 64-bit)
+enum CounterWord { C_NODE_VISITS, C_PRIM_TESTS, C_RAYS_CLOSEST, C_RAYS_SHADOW, C_BOUNCES, C_NUM_WORDS = 8 };
+
+}  // namespace tk

@@ -1,0 +1,310 @@
+// tk_shade.h — per-vertex work of the integrator as device functions: hit attributes, textures,
+// the 12-way material dispatch (a switch on the tag the queue was sorted by), area-light sampling.
+//
+// Functional counterparts in the reference (the formulas and branch conditions are kept exactly, because
+// they define the estimator; the dispatch, data layout and control flow are not):
+//   hit attributes    src/shape.cpp:30-40, 80-108      textures   src/texture.cpp:3-25
+//   materials         src/material.cpp:76-98 + src/materials/*.inl, src/material.h:121-140
+//   lights            src/light.cpp:5-7,32-56, src/shape.cpp:125-184
+#pragma once
+
+#include "tk_scene.h"
+#include "tk_traverse.h"
+
+namespace tk {
+
+template <class R> struct Isect {  // reference `Intersection` (src/intersection.h:4-12)
+    Vec3<R> pos, gn, sn;
+    Vec2<R> uv;
+    int32_t material, area_light;
+};
+
+template <class R> TK_HD Vec3<R> ld3(const R *p) { return {p[0], p[1], p[2]}; }
+
+// Rebuild the full intersection record from (primitive, t, u, v) and the ray: src/shape.cpp:30-40 (sphere),
+// :80-108 (triangle).  `prim` indexes the leaf-ordered primitive records (the closest-hit kernel reports it);
+// vertex attributes come from the shading-side arrays through the shape id stored in the record.
+template <class R>
+TK_HD void make_isect(const DeviceScene<R> &sc, Vec3<R> ro, Vec3<R> rd, int32_t prim, R t, R u, R v, Isect<R> &out) {
+    const PrimRec<R> &p = sc.prims[prim];
+    const ShapeInfo si = sc.shapes[p.shape_id];
+    out.material = si.material;
+    out.area_light = si.area_light;
+    out.pos = ro + rd * t;
+    if (si.mesh < 0) {
+        Vec3<R> n = normalize(out.pos - Vec3<R>{p.a[0], p.a[1], p.a[2]});
+        n = dot(rd, n) < R(0) ? n : -n;
+        out.gn = n;
+        out.sn = n;
+        R theta = tk_acos(-n.y);  // get_sphere_uv, src/shape.cpp:3-11
+        R phi = tk_atan2(-n.z, n.x) + Const<R>::PI;
+        out.uv = {phi / (R(2) * Const<R>::PI), -theta / Const<R>::PI};
+        return;
+    }
+    Vec3<R> e1{p.a[3], p.a[4], p.a[5]}, e2{p.a[6], p.a[7], p.a[8]};
+    Vec3<R> gn = normalize(cross(e1, e2));
+    gn = dot(rd, gn) < R(0) ? gn : -gn;
+    out.gn = gn;
+    const MeshInfo mi = sc.meshes[si.mesh];
+    const int32_t *idx = sc.face_idx + 3 * (int64_t)(mi.fbase + si.face);
+    const int32_t i0 = idx[0], i1 = idx[1], i2 = idx[2];
+    if (mi.uvbase < 0) {
+        out.uv = {u, v};
+    } else {
+        const R *uv = sc.uvs + 2 * (int64_t)mi.uvbase;
+        Vec2<R> uv0{uv[2 * i0], uv[2 * i0 + 1]}, uv1{uv[2 * i1], uv[2 * i1 + 1]}, uv2{uv[2 * i2], uv[2 * i2 + 1]};
+        out.uv = (R(1) - u - v) * uv0 + u * uv1 + v * uv2;
+    }
+    if (mi.nbase < 0) {
+        out.sn = gn;
+    } else {
+        const R *nn = sc.normals + 3 * (int64_t)mi.nbase;
+        Vec3<R> n0 = ld3(nn + 3 * i0), n1 = ld3(nn + 3 * i1), n2 = ld3(nn + 3 * i2);
+        out.sn = normalize((R(1) - u - v) * n0 + u * n1 + v * n2);
+    }
+}
+
+// ---- textures (src/texture.cpp:3-25; the wrap-seam arithmetic of :13-24 is kept as is)
+template <class R> TK_HD R modulo1(R a) {
+    R r = tk_fmod(a, R(1));
+    return (r < R(0)) ? r + R(1) : r;
+}
+template <class R> TK_HD Vec3<R> eval_texture(const DeviceScene<R> &sc, const MaterialRec<R> &m, Vec2<R> uv) {
+    if (m.tex_kind == 0) return ld3(m.color);
+    const ImageInfo im = sc.images[m.tex_image];
+    R x = R(im.width) * modulo1(m.uscale * uv.x + m.uoffset);
+    R y = R(im.height) * modulo1(m.vscale * uv.y + m.voffset);
+    int x1 = (int)tk_floor(x);
+    int x2 = (x1 + 1) == im.width ? 0 : (x1 + 1);
+    int y1 = (int)tk_floor(y);
+    int y2 = (y1 + 1) == im.height ? 0 : (y1 + 1);
+    const R *tx = sc.texels + 3 * im.offset;
+    Vec3<R> q11 = ld3(tx + 3 * ((int64_t)y1 * im.width + x1)), q12 = ld3(tx + 3 * ((int64_t)y2 * im.width + x1));
+    Vec3<R> q21 = ld3(tx + 3 * ((int64_t)y1 * im.width + x2)), q22 = ld3(tx + 3 * ((int64_t)y2 * im.width + x2));
+    if (x1 == x2) x2 += 1;
+    if (y1 == y2) y2 += 1;
+    R fx2 = R(x2) - x, fx1 = x - R(x1), fy2 = R(y2) - y, fy1 = y - R(y1);
+    return (q11 * fx2 * fy2 + q21 * fx1 * fy2 + q12 * fx2 * fy1 + q22 * fx1 * fy1) / R((x2 - x1) * (y2 - y1));
+}
+
+// ---- materials
+template <class R> struct BsdfSample {
+    Vec3<R> dir_out;
+    R pdf;
+};
+template <class R> TK_HD Vec3<R> facing(Vec3<R> dir_in, const Isect<R> &v) {
+    return dot(dir_in, v.sn) < R(0) ? -v.sn : v.sn;
+}
+template <class R> TK_HD Vec3<R> hemisphere_cos(Rng &rng) {  // src/material.h:121-132
+    R u1 = random_real<R>(rng);
+    R u2 = random_real<R>(rng);
+    R phi = Const<R>::TWOPI * u2;
+    R s = tk_sqrt(tk_clamp(u1, R(0), R(1)));
+    return {tk_cos(phi) * s, tk_sin(phi) * s, tk_sqrt(tk_clamp(R(1) - u1, R(0), R(1)))};
+}
+template <class R> TK_HD Vec3<R> power_lobe(R exponent, Rng &rng) {  // src/materials/phong.inl:7-18
+    R u1 = random_real<R>(rng);
+    R u2 = random_real<R>(rng);
+    R ra1 = R(1) / (exponent + R(1));
+    R phi = Const<R>::TWOPI * u2;
+    R s = tk_sqrt(tk_clamp(R(1) - tk_pow(u1, R(2) * ra1), R(0), R(1)));
+    return normalize(Vec3<R>{tk_cos(phi) * s, tk_sin(phi) * s, tk_clamp(tk_pow(u1, ra1), R(0), R(1))});
+}
+template <class R> TK_HD R g_hat(Vec3<R> w, Vec3<R> n, R alpha) {  // src/material.h:134-140
+    R odn = dot(w, n);
+    R a = tk_sqrt(R(0.5) * alpha + R(1)) / tk_sqrt(R(1) / (odn * odn) - R(1));
+    R a2 = a * a;
+    return a < R(1.6) ? (R(3.535) * a + R(2.181) * a2) / (R(1) + R(2.276) * a + R(2.577) * a2) : R(1);
+}
+template <class R> TK_HD BsdfSample<R> cosine_sample(Vec3<R> n, const Isect<R> &v, Vec3<R> local) {
+    BsdfSample<R> s;
+    s.dir_out = to_world(n, local);
+    s.pdf = dot(v.gn, s.dir_out) < R(0) ? R(0) : tk_fmax(dot(n, s.dir_out), R(0)) / Const<R>::PI;
+    return s;
+}
+
+// returns false when the reference returns an empty optional (dir_in below the geometric surface)
+template <class R>
+TK_HD bool sample_bsdf(const MaterialRec<R> &m, Vec3<R> dir_in, const Isect<R> &v, Rng &rng, BsdfSample<R> &out) {
+    if (dot(v.gn, dir_in) < R(0)) return false;
+    const Vec3<R> n = facing(dir_in, v);
+    switch (m.tag) {
+        case 1: {  // Mirror
+            out.dir_out = -dir_in + R(2) * dot(dir_in, n) * n;
+            out.pdf = R(1);
+            return true;
+        }
+        case 2: {  // Plastic
+            Vec3<R> refl = -dir_in + R(2) * dot(dir_in, n) * n;
+            R F0 = tk_pow((m.p0 - R(1)) / (m.p0 + R(1)), R(2));
+            R F = F0 + (R(1) - F0) * tk_pow(R(1) - dot(n, refl), R(5));
+            R u = random_real<R>(rng);
+            if (u <= F) {
+                out.dir_out = refl;
+                out.pdf = R(1);
+            } else {
+                out = cosine_sample(n, v, hemisphere_cos<R>(rng));
+            }
+            return true;
+        }
+        case 3: {  // Phong
+            Vec3<R> local = power_lobe<R>(m.p0, rng);
+            Vec3<R> refl = normalize(-dir_in + R(2) * dot(dir_in, n) * n);
+            out.dir_out = normalize(to_world(refl, local));
+            out.pdf = dot(v.gn, out.dir_out) < R(0)
+                          ? R(0)
+                          : tk_fmax(R(0), (m.p0 + R(1)) / Const<R>::TWOPI * tk_pow(dot(refl, out.dir_out), m.p0));
+            return true;
+        }
+        case 4:    // BlinnPhong
+        case 5: {  // BlinnPhongMicrofacet
+            Vec3<R> h = normalize(to_world(n, power_lobe<R>(m.p0, rng)));
+            out.dir_out = normalize(-dir_in + R(2) * dot(dir_in, h) * h);
+            if (dot(v.gn, out.dir_out) <= R(0) || dot(h, n) <= R(0) || dot(out.dir_out, h) <= R(0)) {
+                out.pdf = R(0);
+            } else {
+                R ndh = m.tag == 4 ? dot(n, h) : tk_clamp(dot(n, h), R(0), R(1));
+                out.pdf = (m.p0 + R(1)) * R(0.25) * Const<R>::INVTWOPI * tk_pow(ndh, m.p0) / dot(out.dir_out, h);
+            }
+            return true;
+        }
+        default:  // Diffuse and the Disney family: cosine hemisphere
+            out = cosine_sample(n, v, hemisphere_cos<R>(rng));
+            return true;
+    }
+}
+
+template <class R> TK_HD R bsdf_pdf(const MaterialRec<R> &m, Vec3<R> dir_in, Vec3<R> dir_out, const Isect<R> &v) {
+    if (m.tag == 1) return R(0);
+    if (dot(v.gn, dir_out) < R(0)) return R(0);
+    const Vec3<R> n = facing(dir_in, v);
+    switch (m.tag) {
+        case 2: {
+            R F0 = tk_pow((m.p0 - R(1)) / (m.p0 + R(1)), R(2));
+            R F = F0 + (R(1) - F0) * tk_pow(R(1) - dot(n, dir_out), R(5));
+            return (R(1) - F) * tk_fmax(dot(n, dir_out), R(0)) / Const<R>::PI;
+        }
+        case 3: {
+            Vec3<R> refl = normalize(-dir_in + R(2) * dot(dir_in, n) * n);
+            return tk_fmax(R(0), (m.p0 + R(1)) / Const<R>::TWOPI * tk_pow(dot(refl, dir_out), m.p0));
+        }
+        case 4:
+        case 5: {
+            Vec3<R> h = normalize(dir_out + dir_in);
+            if (dot(v.gn, dir_out) <= R(0) || dot(h, n) <= R(0) || dot(dir_out, h) <= R(0)) return R(0);
+            R ndh = m.tag == 4 ? dot(n, h) : tk_clamp(dot(n, h), R(0), R(1));
+            return (m.p0 + R(1)) * R(0.25) * Const<R>::INVTWOPI * tk_pow(ndh, m.p0) / dot(dir_out, h);
+        }
+        default:
+            return tk_fmax(dot(n, dir_out), R(0)) / Const<R>::PI;
+    }
+}
+
+// BSDF * cosine ("FG").  rec_pdf is SampleRecord::pdf: Plastic's specular branch is recognised by pdf == 1
+// (src/materials/plastic.inl:44).
+template <class R>
+TK_HD Vec3<R> eval_bsdf(const DeviceScene<R> &sc, const MaterialRec<R> &m, Vec3<R> dir_in, Vec3<R> dir_out, R rec_pdf,
+                        const Isect<R> &v) {
+    const Vec3<R> zero{R(0), R(0), R(0)};
+    if (dot(v.gn, dir_in) < R(0) || dot(v.gn, dir_out) < R(0)) return zero;
+    const Vec3<R> n = facing(dir_in, v);
+    switch (m.tag) {
+        case 1: {
+            Vec3<R> F0 = eval_texture(sc, m, v.uv);
+            return F0 + one_minus(F0) * tk_pow5(R(1) - dot(n, dir_out));
+        }
+        case 2: {
+            if (rec_pdf == R(1)) return {R(1), R(1), R(1)};
+            Vec3<R> Kd = eval_texture(sc, m, v.uv);
+            return Kd * tk_fmax(dot(n, dir_out), R(0)) / Const<R>::PI;
+        }
+        case 3: {
+            Vec3<R> refl = normalize(-dir_in + R(2) * dot(dir_in, n) * n);
+            Vec3<R> Ks = eval_texture(sc, m, v.uv);
+            if (dot(n, dir_out) <= R(0)) return zero;
+            return Ks * (m.p0 + R(1)) / Const<R>::TWOPI * tk_pow(tk_fmax(dot(dir_out, refl), R(0)), m.p0);
+        }
+        case 4: {
+            if (dot(n, dir_out) <= R(0)) return zero;
+            Vec3<R> h = normalize(dir_out + dir_in);
+            Vec3<R> Ks = eval_texture(sc, m, v.uv);
+            Vec3<R> Fh = Ks + one_minus(Ks) * tk_pow5(R(1) - dot(h, dir_out));
+            R norm = (m.p0 + R(2)) * R(0.25) * Const<R>::INVPI / (R(2) - tk_pow(R(2), -m.p0 / R(2)));
+            return norm * Fh * tk_pow(tk_fmax(R(0), dot(n, h)), m.p0);
+        }
+        case 5: {
+            Vec3<R> h = normalize(dir_out + dir_in);
+            if (dot(n, dir_out) <= R(0) || dot(dir_out, h) <= R(0) || dot(dir_in, h) <= R(0)) return zero;
+            Vec3<R> Ks = eval_texture(sc, m, v.uv);
+            Vec3<R> Fh = Ks + one_minus(Ks) * tk_pow5(R(1) - dot(h, dir_out));
+            R Dh = (m.p0 + R(2)) * Const<R>::INVTWOPI * tk_pow(tk_clamp(dot(n, h), R(0), R(1)), m.p0);
+            R G = g_hat(dir_out, n, m.p0) * g_hat(dir_in, n, m.p0);
+            return Fh * Dh * G * R(0.25) / dot(n, dir_in);
+        }
+        case 6: {  // DisneyDiffuse, src/materials/disney_diffuse.inl:22-46
+            Vec3<R> h = normalize(dir_in + dir_out);
+            R hdout = dot(h, dir_out), ndout = dot(n, dir_out), ndin = dot(n, dir_in);
+            Vec3<R> Kd = eval_texture(sc, m, v.uv);
+            R fd90 = R(0.5) + R(2) * m.p0 * hdout * hdout;
+            R fi = R(1) + (fd90 - R(1)) * tk_pow(R(1) - dot(n, dir_in), R(5));
+            R fo = R(1) + (fd90 - R(1)) * tk_pow(R(1) - dot(n, dir_out), R(5));
+            Vec3<R> base = Kd * Const<R>::INVPI * fi * fo * ndout;
+            R fss90 = m.p0 * hdout * hdout;
+            R si = R(1) + (fss90 - R(1)) * tk_pow(R(1) - dot(n, dir_in), R(5));
+            R so = R(1) + (fss90 - R(1)) * tk_pow(R(1) - dot(n, dir_out), R(5));
+            Vec3<R> ss = R(1.25) * Kd * Const<R>::INVPI *
+                         (si * so * (R(1) / (tk_fabs(ndin) + tk_fabs(ndout)) - R(0.5)) + R(0.5)) * ndout;
+            return (R(1) - m.p1) * base + m.p1 * ss;
+        }
+        case 9:  // DisneyClearcoat: the reference returns an uninitialised value; defined as zero
+            return zero;
+        default: {
+            Vec3<R> Kd = eval_texture(sc, m, v.uv);
+            return Kd * tk_fmax(dot(n, dir_out), R(0)) / Const<R>::PI;
+        }
+    }
+}
+
+// ---- lights
+template <class R> struct LightSample {
+    Vec3<R> pos, n;
+};
+template <class R> TK_HD LightSample<R> sample_light_point(const LightRec<R> &l, Vec3<R> ref, Rng &rng) {
+    LightSample<R> s;
+    R u1 = random_real<R>(rng);
+    R u2 = random_real<R>(rng);
+    if (l.is_sphere) {  // cone sampling, src/shape.cpp:125-144
+        Vec3<R> c = ld3(l.v);
+        R r = l.v[3];
+        R d = length(c - ref);
+        R z = R(1) + u1 * (r / d - R(1));
+        R z2 = z * z;
+        R st = tk_sqrt(tk_clamp(R(1) - z2, R(0), R(1)));
+        Vec3<R> local = normalize(Vec3<R>{tk_cos(R(2) * Const<R>::PI * u2) * st, tk_sin(R(2) * Const<R>::PI * u2) * st, z});
+        s.n = normalize(to_world(normalize(ref - c), local));
+        s.pos = c + r * s.n;
+        return s;
+    }
+    Vec3<R> v0 = ld3(l.v), v1 = ld3(l.v + 3), v2 = ld3(l.v + 6);  // src/shape.cpp:146-169
+    R b1 = R(1) - tk_sqrt(u1);
+    R b2 = tk_sqrt(u1) * u2;
+    s.pos = (R(1) - b1 - b2) * v0 + b1 * v1 + b2 * v2;
+    Vec3<R> gn = normalize(cross(v1 - v0, v2 - v0));
+    Vec3<R> sn = (R(1) - b1 - b2) * ld3(l.n) + b1 * ld3(l.n + 3) + b2 * ld3(l.n + 6);
+    s.n = dot(sn, gn) > R(0) ? gn : -gn;
+    return s;
+}
+// area-measure pdf of a point on light `l` seen from ref (src/light.cpp:32-48; the sphere branch measures d
+// to the light POINT, as the reference does)
+template <class R> TK_HD R light_pdf_area(const LightRec<R> &l, Vec3<R> light_pos, Vec3<R> ref) {
+    if (l.kind != 1) return R(0);
+    if (l.is_sphere) {
+        R r = l.v[3];
+        R d = length(light_pos - ref);
+        return R(1) / (Const<R>::TWOPI * r * r * (R(1) - r / d));
+    }
+    Vec3<R> v0 = ld3(l.v), v1 = ld3(l.v + 3), v2 = ld3(l.v + 6);
+    return R(1) / (length(cross(v1 - v0, v2 - v0)) / R(2));
+}
+
+}  // namespace tk

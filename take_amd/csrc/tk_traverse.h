@@ -1,0 +1,182 @@
+// tk_traverse.h — ray/primitive tests and the per-lane wide-BVH traversal.
+//
+// Functional counterpart of the reference's bvh_intersect (src/bvh.cpp:86-109), intersect(BBox,Ray)
+// (src/bbox.h:18-32) and intersect_op (src/shape.cpp:13-80) — redesigned, not transliterated:
+//   * iterative, front-to-back over a 4-wide BVH with a (child, entry distance) stack, culling deferred
+//     subtrees against the current closest hit when they are popped;
+//   * the primitive tests keep the reference's exact decision sequence and IEEE operation order (epsilon
+//     determinant cull, inclusive [tmin, tmax], u/v/u+v bounds) so that t,u,v of a hit are bit-identical
+//     to the f32/f64 restatement in oracle/;
+//   * the box test is conservative (both planes widened by a few ulp), so a different tree shape cannot
+//     lose a hit the reference's tree finds; closest hit is then tree-independent up to exact ties;
+//   * shadow rays stop at the first hit (scene_occluded only uses the boolean, src/scene.cpp:49-53).
+#pragma once
+
+#include "tk_scene.h"
+
+namespace tk {
+
+template <class R> struct RayT {
+    Vec3<R> o, d;
+    R tmin, tmax;
+};
+template <class R> struct HitT {
+    int32_t shape;  // -1 = miss
+    int32_t prim;   // index of the hit primitive in leaf order (-1 = miss)
+    int32_t meta;   // PrimRec::meta of the hit primitive
+    R t, u, v;
+};
+
+// Möller–Trumbore, decision sequence of src/shape.cpp:52-78.  tmax is the current closest distance.
+template <class R> TK_HD bool tri_test(const R *a, const RayT<R> &r, R tmax, R &t, R &u, R &v) {
+    Vec3<R> v0{a[0], a[1], a[2]}, e1{a[3], a[4], a[5]}, e2{a[6], a[7], a[8]};
+    Vec3<R> h = cross(r.d, e2);
+    R det = dot(e1, h);
+    if (det > -Const<R>::DET_EPS && det < Const<R>::DET_EPS) return false;
+    R f = R(1.0) / det;
+    Vec3<R> s = r.o - v0;
+    u = f * dot(s, h);
+    if (u < R(0.0) || u > R(1.0)) return false;
+    Vec3<R> q = cross(s, e1);
+    v = f * dot(r.d, q);
+    if (v < R(0.0) || u + v > R(1.0)) return false;
+    t = f * dot(e2, q);
+    if (t < r.tmin || tmax < t) return false;
+    return true;
+}
+// src/shape.cpp:13-29
+template <class R> TK_HD bool sphere_test(const R *a, const RayT<R> &r, R tmax, R &t) {
+    Vec3<R> c{a[0], a[1], a[2]};
+    R radius = a[3];
+    Vec3<R> oc = r.o - c;
+    R qa = dot(r.d, r.d);
+    R half_b = dot(oc, r.d);
+    R qc = dot(oc, oc) - radius * radius;
+    R disc = half_b * half_b - qa * qc;
+    if (disc < R(0)) return false;
+    R sqrtd = tk_sqrt(disc);
+    R root = (-half_b - sqrtd) / qa;
+    if (root < r.tmin || tmax < root) {
+        root = (-half_b + sqrtd) / qa;
+        if (root < r.tmin || tmax < root) return false;
+    }
+    t = root;
+    return true;
+}
+
+template <class R> TK_HD R safe_inv(R d) {
+    const R tiny = R(1e-30);
+    R ad = tk_fabs(d);
+    R dd = ad > tiny ? d : __builtin_copysign(tiny, d);
+    return R(1) / dd;
+}
+TK_HD float stack_key(float t) { return t; }
+TK_HD float stack_key(double t) {  // largest float <= t: keeps pop-time culling conservative in f64 mode
+    float f = (float)t;
+    if ((double)f > t) {  // step one float towards -inf (entry distances are finite and >= tmin > 0)
+        union {
+            float f;
+            uint32_t u;
+        } b;
+        b.f = f;
+        b.u = f > 0.0f ? b.u - 1u : (f < 0.0f ? b.u + 1u : 0x80000001u);
+        f = b.f;
+    }
+    return f;
+}
+
+struct TravCount {
+    uint32_t nodes = 0, prims = 0;
+};
+
+// Stack concept: void push(int level, int32_t child, float key); void pop(int level, int32_t&, float&)
+template <class R, bool ANY_HIT, bool COUNT, class Stack>
+TK_HD void traverse(const DeviceScene<R> &sc, const RayT<R> &ray, Stack &stack, HitT<R> &hit, TravCount &tc) {
+    hit.shape = -1;
+    hit.prim = -1;
+    hit.meta = 0;
+    hit.t = ray.tmax;
+    hit.u = hit.v = R(0);
+    const R idx = safe_inv(ray.d.x), idy = safe_inv(ray.d.y), idz = safe_inv(ray.d.z);
+    R tbest = ray.tmax;
+    int sp = 0;
+    int32_t cur = sc.root_child;
+    for (;;) {
+        if (cur >= 0) {
+            const Node4<R> &n = sc.nodes[cur];
+            if (COUNT) tc.nodes++;
+            R key[4];
+            int32_t ch[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                R t0x = (n.bmin[0][i] - ray.o.x) * idx, t1x = (n.bmax[0][i] - ray.o.x) * idx;
+                R t0y = (n.bmin[1][i] - ray.o.y) * idy, t1y = (n.bmax[1][i] - ray.o.y) * idy;
+                R t0z = (n.bmin[2][i] - ray.o.z) * idz, t1z = (n.bmax[2][i] - ray.o.z) * idz;
+                R tn = tk_fmax(tk_fmax(tk_fmin(t0x, t1x), tk_fmin(t0y, t1y)), tk_fmax(tk_fmin(t0z, t1z), ray.tmin));
+                R tf = tk_fmin(tk_fmin(tk_fmax(t0x, t1x), tk_fmax(t0y, t1y)), tk_fmin(tk_fmax(t0z, t1z), tbest));
+                // widen by a few ulp on both sides (t >= tmin > 0 on the path, so scaling is monotone)
+                bool ok = (tn * Const<R>::BOX_SHRINK <= tf * Const<R>::BOX_GROW) && (n.child[i] != CHILD_EMPTY);
+                key[i] = ok ? tn : Const<R>::inf();
+                ch[i] = n.child[i];
+            }
+            // sorting network, ascending by entry distance
+#define TK_CSWAP(a, b)                        \
+    {                                         \
+        bool sw = key[b] < key[a];            \
+        R ka = sw ? key[b] : key[a];          \
+        R kb = sw ? key[a] : key[b];          \
+        int32_t ca = sw ? ch[b] : ch[a];      \
+        int32_t cb = sw ? ch[a] : ch[b];      \
+        key[a] = ka, key[b] = kb, ch[a] = ca, ch[b] = cb; \
+    }
+            TK_CSWAP(0, 1) TK_CSWAP(2, 3) TK_CSWAP(0, 2) TK_CSWAP(1, 3) TK_CSWAP(1, 2)
+#undef TK_CSWAP
+            // far to near: deferred children go on the stack, the nearest is visited next
+            if (key[3] < Const<R>::inf()) stack.push(sp++, ch[3], stack_key(key[3]));
+            if (key[2] < Const<R>::inf()) stack.push(sp++, ch[2], stack_key(key[2]));
+            if (key[1] < Const<R>::inf()) stack.push(sp++, ch[1], stack_key(key[1]));
+            if (key[0] < Const<R>::inf()) {
+                cur = ch[0];
+                continue;
+            }
+        } else if (cur != CHILD_EMPTY) {
+            const int first = leaf_first(cur), cnt = leaf_count(cur);
+            for (int k = 0; k < cnt; k++) {
+                const PrimRec<R> &p = sc.prims[first + k];
+                if (COUNT) tc.prims++;
+                R t, u = R(0), v = R(0);
+                bool ok = ((p.meta & 0xff) == PRIM_TRIANGLE) ? tri_test(p.a, ray, tbest, t, u, v)
+                                                             : sphere_test(p.a, ray, tbest, t);
+                if (ok) {
+                    tbest = t;
+                    hit.shape = p.shape_id;
+                    hit.prim = first + k;
+                    hit.meta = p.meta;
+                    hit.t = t;
+                    hit.u = u;
+                    hit.v = v;
+                    if (ANY_HIT) return;
+                }
+            }
+        }
+        // pop the next deferred subtree that can still contain a closer hit
+        for (;;) {
+            if (sp == 0) return;
+            float k;
+            stack.pop(--sp, cur, k);
+            if ((R)k <= tbest) break;
+        }
+    }
+}
+
+// make a ray record from raw components
+template <class R> TK_HD RayT<R> make_ray(R ox, R oy, R oz, R dx, R dy, R dz, R tmin, R tmax) {
+    RayT<R> r;
+    r.o = {ox, oy, oz};
+    r.d = {dx, dy, dz};
+    r.tmin = tmin;
+    r.tmax = tmax;
+    return r;
+}
+
+}  // namespace tk

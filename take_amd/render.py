@@ -1,0 +1,51 @@
+"""Host-side mirror of the reference's `render()` (src/render.h:5, src/render.cpp:9-86).
+
+Same argument convention — a parameter list holding a scene file and an optional `-max_depth D`
+(default 50, src/render.cpp:14) — and the same result: the image in `Image3` layout (row 0 = top,
+`img(x, y)` at [y, x, :]).  The scene file is a `.tkscene`, i.e. a reference `Scene` flattened by
+take_amd/host/take_flatten.hpp after the reference's own XML parser ran (the parser is outside this path).
+All rendering happens in libtake_hip.so on the current HIP device; without it the call raises.
+"""
+import numpy as np
+
+from . import cdefs as D
+from .capi import Scene
+from .scene import SceneData, load_tkscene
+
+
+def parse_params(params):
+    """argument handling of src/render.cpp:14-23"""
+    max_depth = 50
+    filename = None
+    i = 0
+    while i < len(params):
+        if params[i] == "-max_depth":
+            i += 1
+            max_depth = int(params[i])
+        elif filename is None:
+            filename = params[i]
+        i += 1
+    return filename, max_depth
+
+
+def render(params, seed=0, precision=D.TAKE_PRECISION_F32, ray_epsilon=0.0):
+    """render(["scene.tkscene", "-max_depth", "5"]) -> (H, W, 3) numpy image (float32, or float64 in f64 mode).
+    An empty parameter list returns an empty image, as the reference does (src/render.cpp:10-12)."""
+    if len(params) < 1:
+        return np.zeros((0, 0, 3), np.float32)
+    filename, max_depth = parse_params(list(params))
+    sd = filename if isinstance(filename, SceneData) else load_tkscene(filename)
+    scene = Scene(sd, precision=precision)
+    try:
+        return scene.render(spp=sd.spp, max_depth=max_depth, seed=seed, ray_epsilon=ray_epsilon)
+    finally:
+        scene.close()
+
+
+def imwrite_pfm(path, img):
+    """PFM as the reference writes it (src/image.cpp:145-153): header `PF\\nW H\\n-1\\n`, float32 RGB rows in
+    Image3 order."""
+    a = np.ascontiguousarray(img, np.float32)
+    with open(path, "wb") as f:
+        f.write(b"PF\n%d %d\n-1\n" % (a.shape[1], a.shape[0]))
+        f.write(a.tobytes())

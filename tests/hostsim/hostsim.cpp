@@ -1,0 +1,169 @@
+// hostsim.cpp — TEST INFRASTRUCTURE.  Serial host re-execution of the *device* code paths of take_amd/csrc:
+// the same tk_host_scene.h (scene preparation + wide BVH), tk_traverse.h, tk_shade.h and tk_integrate.h that
+// the HIP kernels call, driven by plain loops in the same round order as the kernels of tk_kernels.h.
+//
+// Purpose: debug the product's device logic on a machine without a GPU (the authoring container) by comparing
+// it with the oracle at small sizes.  It is compiled only by tests/ (tests/hostsim/Makefile), is not part of
+// take_amd/ and is never loaded by the product: libtake_hip.so has no CPU path.
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "take_hip.h"
+#include "tk_host_scene.h"
+#include "tk_integrate.h"
+
+using namespace tk;
+
+namespace {
+struct ArrayStack {
+    int32_t child[128];
+    float key[128];
+    int max_level = 0;
+    void push(int level, int32_t c, float k) {
+        child[level] = c;
+        key[level] = k;
+        if (level + 1 > max_level) max_level = level + 1;
+    }
+    void pop(int level, int32_t &c, float &k) {
+        c = child[level];
+        k = key[level];
+    }
+};
+std::string g_err;
+
+template <class R> int render_t(const TakeSceneDesc &desc, const TakeRenderOpts &o, void *out_v, uint64_t *stats) {
+    HostScene<R> hs;
+    g_err = prepare_scene<R>(desc, 0, 1, hs);
+    if (!g_err.empty()) return TAKE_E_INVALID;
+    DeviceScene<R> sc = hs.view();
+    const int W = hs.cam.width, H = hs.cam.height;
+    const int stride = o.strip_stride > 0 ? o.strip_stride : 1;
+    const int n_strips = (H + TILE_ROWS - 1) / TILE_ROWS;
+    int n_rows = 0;
+    for (int s = o.strip_first; s < n_strips; s += stride) n_rows += std::min(H, (s + 1) * TILE_ROWS) - s * TILE_ROWS;
+    const int64_t npix = (int64_t)n_rows * W;
+    RenderParams<R> rp{};
+    rp.width = W, rp.height = H, rp.n_local_rows = n_rows, rp.npix = (int32_t)npix;
+    rp.strip_first = o.strip_first, rp.strip_stride = stride;
+    rp.spp = o.spp, rp.max_depth = o.max_depth, rp.seed = o.seed;
+    rp.ray_eps = o.ray_epsilon > 0 ? R(o.ray_epsilon) : (sizeof(R) == 8 ? R(1e-7) : R(1e-4));
+    const int spb = o.samples_per_batch > 0 ? std::min(o.samples_per_batch, o.spp) : o.spp;
+    const int64_t slots = (int64_t)spb * npix;
+    std::vector<R> sr((size_t)S_NUM_R * slots);
+    std::vector<int32_t> si((size_t)S_NUM_I * slots);
+    PathState<R> st{sr.data(), si.data(), slots};
+    std::vector<R> accum(3 * npix, R(0));
+    std::vector<int32_t> q[2], shadow;
+    uint64_t n_closest = 0, n_shadow = 0, n_nodes = 0, n_prims = 0, max_stack = 0;
+    for (int s0 = 0; s0 < o.spp; s0 += spb) {
+        const int nb = std::min(spb, o.spp - s0);
+        const int64_t n = (int64_t)nb * npix;
+        rp.s0 = s0;
+        rp.spb = nb;
+        q[0].clear();
+        for (int64_t s = 0; s < n; s++) {
+            generate_path(sc, rp, st, s);
+            q[0].push_back((int32_t)s);
+        }
+        for (int k = 0; k < o.max_depth + 2; k++) {
+            const int cur = k & 1, next = cur ^ 1;
+            q[next].clear();
+            shadow.clear();
+            for (int32_t slot : q[cur]) {  // k_trace<closest>
+                RayT<R> ray = make_ray(st.R_(S_OX, slot), st.R_(S_OY, slot), st.R_(S_OZ, slot), st.R_(S_DX, slot),
+                                       st.R_(S_DY, slot), st.R_(S_DZ, slot), rp.ray_eps, Const<R>::inf());
+                HitT<R> hit;
+                ArrayStack stack;
+                TravCount tc;
+                traverse<R, false, true>(sc, ray, stack, hit, tc);
+                n_nodes += tc.nodes, n_prims += tc.prims, n_closest++;
+                max_stack = std::max<uint64_t>(max_stack, stack.max_level);
+                st.I_(S_HIT, slot) = hit.prim;
+                st.R_(S_HT, slot) = hit.t;
+                st.R_(S_HU, slot) = hit.u;
+                st.R_(S_HV, slot) = hit.v;
+            }
+            for (int32_t slot : q[cur]) {  // k_shade
+                uint32_t req = shade_path(sc, rp, st, (int64_t)slot, k);
+                if (req & REQ_EXTEND) q[next].push_back(slot);
+                if (req & REQ_SHADOW) shadow.push_back(slot);
+            }
+            for (int32_t slot : shadow) {  // k_trace<shadow>
+                RayT<R> ray = make_ray(st.R_(S_OX, slot), st.R_(S_OY, slot), st.R_(S_OZ, slot), st.R_(S_SX, slot),
+                                       st.R_(S_SY, slot), st.R_(S_SZ, slot), rp.ray_eps, st.R_(S_ST, slot));
+                HitT<R> hit;
+                ArrayStack stack;
+                TravCount tc;
+                traverse<R, true, true>(sc, ray, stack, hit, tc);
+                n_nodes += tc.nodes, n_prims += tc.prims, n_shadow++;
+                if (hit.prim < 0) {
+                    st.R_(S_LX, slot) = st.R_(S_LX, slot) + st.R_(S_CX, slot);
+                    st.R_(S_LY, slot) = st.R_(S_LY, slot) + st.R_(S_CY, slot);
+                    st.R_(S_LZ, slot) = st.R_(S_LZ, slot) + st.R_(S_CZ, slot);
+                }
+            }
+            if (q[next].empty()) break;
+        }
+        for (int64_t p = 0; p < npix; p++)  // k_accumulate
+            for (int s = 0; s < nb; s++) {
+                const int64_t slot = (int64_t)s * npix + p;
+                accum[3 * p] = accum[3 * p] + st.R_(S_LX, slot);
+                accum[3 * p + 1] = accum[3 * p + 1] + st.R_(S_LY, slot);
+                accum[3 * p + 2] = accum[3 * p + 2] + st.R_(S_LZ, slot);
+            }
+    }
+    R *out = (R *)out_v;  // k_resolve
+    const R inv = R(1) / R(o.spp);
+    for (int64_t p = 0; p < npix; p++) {
+        const int lr = (int)(p / W), x = (int)(p % W);
+        const int64_t oidx = 3 * ((int64_t)(n_rows - 1 - lr) * W + x);
+        for (int c = 0; c < 3; c++) out[oidx + c] = accum[3 * p + c] * inv;
+    }
+    if (stats) {
+        stats[0] = n_closest, stats[1] = n_shadow, stats[2] = n_nodes, stats[3] = n_prims, stats[4] = max_stack;
+        stats[5] = (uint64_t)hs.stats.n_nodes, stats[6] = (uint64_t)hs.stats.depth;
+    }
+    return TAKE_OK;
+}
+
+template <class R> int trace_t(const TakeSceneDesc &desc, const void *rays_v, int64_t n, void *hits_v, int any) {
+    HostScene<R> hs;
+    g_err = prepare_scene<R>(desc, 0, 1, hs);
+    if (!g_err.empty()) return TAKE_E_INVALID;
+    DeviceScene<R> sc = hs.view();
+    const R *rays = (const R *)rays_v;  // org3 tmin dir3 tmax
+    R *hits = (R *)hits_v;              // shape t u v  (shape as R)
+    for (int64_t i = 0; i < n; i++) {
+        const R *q = rays + 8 * i;
+        RayT<R> ray = make_ray(q[0], q[1], q[2], q[4], q[5], q[6], q[3], q[7]);
+        HitT<R> hit;
+        ArrayStack stack;
+        TravCount tc;
+        if (any)
+            traverse<R, true, false>(sc, ray, stack, hit, tc);
+        else
+            traverse<R, false, false>(sc, ray, stack, hit, tc);
+        hits[4 * i] = R(hit.shape);
+        hits[4 * i + 1] = hit.prim >= 0 ? hit.t : R(0);
+        hits[4 * i + 2] = hit.u;
+        hits[4 * i + 3] = hit.v;
+    }
+    return TAKE_OK;
+}
+}  // namespace
+
+extern "C" {
+const char *hostsim_last_error(void) { return g_err.c_str(); }
+// out: rows*W*3 Real (float for f32, double for f64); stats: 7 words (may be null)
+int hostsim_render(const TakeSceneDesc *desc, int precision, const TakeRenderOpts *opts, void *out, uint64_t *stats) {
+    return precision == TAKE_PRECISION_F64 ? render_t<double>(*desc, *opts, out, stats)
+                                           : render_t<float>(*desc, *opts, out, stats);
+}
+// rays: n x 8 Real laid out as TakeRayF/TakeRayD; hits: n x 4 Real (shape id as Real, t, u, v)
+int hostsim_trace(const TakeSceneDesc *desc, int precision, const void *rays, int64_t n, void *hits, int any) {
+    return precision == TAKE_PRECISION_F64 ? trace_t<double>(*desc, rays, n, hits, any)
+                                           : trace_t<float>(*desc, rays, n, hits, any);
+}
+}

@@ -1,0 +1,118 @@
+"""The product's device code, executed on the host (tests/hostsim = the same tk_*.h headers the HIP kernels
+call, driven by serial loops in kernel order), against the oracle.
+
+This is what can be verified without a GPU: scene preparation, the SAH/4-wide BVH, the traversal, the
+integrator rounds, random-stream consumption, strip sharding, batching.  On the host both sides use the same
+libm, so the bar is BIT equality (the GPU tests, which add ocml's libm and the real queues, carry the
+toleranced comparisons)."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import GOLDEN_SCENES, golden_scene, hostsim_render, hostsim_trace, n_local_rows, random_rays
+from take_amd import scenes
+from take_amd.dist import strip_rows
+
+
+@pytest.mark.parametrize("name", GOLDEN_SCENES)
+@pytest.mark.parametrize("precision", [1, 0])
+def test_wide_bvh_closest_hit_equals_exhaustive_search(name, precision):
+    sd = golden_scene(name)
+    rays = random_rays(3000, 5, tmin=1e-7)
+    if precision == 0:
+        rays = rays.astype(np.float32).astype(np.float64)
+    osc = oracle.OracleScene(sd, precision=precision)
+    want = osc.isect_brute(rays)
+    osc.close()
+    got = hostsim_trace(sd, precision, rays).astype(np.float64)
+    assert (got[:, 0] == want[:, 0]).all()
+    hit = want[:, 0] >= 0
+    assert hit.sum() > 1000
+    assert np.array_equal(got[hit, 1:4], want[hit, 1:4])  # t, u, v bit for bit
+
+
+@pytest.mark.parametrize("name", GOLDEN_SCENES)
+def test_any_hit_equals_closest_hit_boolean(name):
+    sd = golden_scene(name)
+    rays = random_rays(3000, 6, bounded_fraction=0.8, tmin=1e-7)
+    osc = oracle.OracleScene(sd, precision=1)
+    want = osc.isect(rays)[:, 15]
+    osc.close()
+    got = hostsim_trace(sd, 1, rays, any_hit=True)[:, 0] >= 0
+    assert np.array_equal(got, want.astype(bool))
+
+
+@pytest.mark.parametrize("name", GOLDEN_SCENES)
+@pytest.mark.parametrize("precision", [1, 0])
+def test_wavefront_render_equals_oracle(name, precision):
+    sd = golden_scene(name)
+    osc = oracle.OracleScene(sd, precision=precision)
+    for depth in (1, 50):
+        want = osc.render(2, depth, rng_mode=oracle.RNG_COUNTER, seed=11, threads=8)
+        got, _ = hostsim_render(sd, precision, 2, depth, seed=11)
+        assert np.array_equal(got.astype(np.float64), want), f"{name} depth {depth}"
+    osc.close()
+
+
+def test_strip_sharding_reassembles_the_full_image():
+    sd = golden_scene("mats")  # 64 x 48: three strips
+    full, _ = hostsim_render(sd, 0, 2, 5, seed=3)
+    for world in (2, 3, 4):
+        img = np.zeros_like(full)
+        total = 0
+        for r in range(world):
+            part, _ = hostsim_render(sd, 0, 2, 5, seed=3, strip_first=r, strip_stride=world)
+            rows = strip_rows(sd.height, r, world)
+            assert part.shape[0] == len(rows) == n_local_rows(sd.height, r, world)
+            img[rows] = part
+            total += len(rows)
+        assert total == sd.height
+        assert np.array_equal(img, full)
+
+
+def test_batching_does_not_change_the_image():
+    sd = golden_scene("cbox")
+    a, _ = hostsim_render(sd, 0, 4, 5, seed=9, samples_per_batch=4)
+    b, _ = hostsim_render(sd, 0, 4, 5, seed=9, samples_per_batch=1)
+    c, _ = hostsim_render(sd, 0, 4, 5, seed=9, samples_per_batch=3)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
+def test_ragged_image_sizes():
+    # width / height not multiples of the tile or the wave
+    sd = golden_scene("cbox")
+    sd.width, sd.height = 37, 21
+    osc = oracle.OracleScene(sd, precision=1)
+    want = osc.render(1, 3, rng_mode=oracle.RNG_COUNTER, seed=2, threads=4)
+    osc.close()
+    got, _ = hostsim_render(sd, 1, 1, 3, seed=2)
+    assert np.array_equal(got, want)
+
+
+def test_max_depth_minus_one_and_zero():
+    sd = golden_scene("cbox")
+    osc = oracle.OracleScene(sd, precision=1)
+    for depth in (-1, 0):
+        want = osc.render(1, depth, rng_mode=oracle.RNG_COUNTER, seed=4, threads=4)
+        got, _ = hostsim_render(sd, 1, 1, depth, seed=4)
+        assert np.array_equal(got, want)
+    osc.close()
+
+
+def test_procedural_soup_scene_matches_oracle():
+    sd = scenes.soup_scene(3000, 48, 32, spp=1, seed=7, jitter=0.05)
+    osc = oracle.OracleScene(sd, precision=0)
+    want = osc.render(1, 50, seed=1, threads=8)
+    osc.close()
+    got, st = hostsim_render(sd, 0, 1, 50, seed=1)
+    assert np.array_equal(got.astype(np.float64), want)
+    assert st["max_stack"] <= 3 * st["bvh_depth"] + 1
+
+
+def test_emissive_mesh_without_normals_is_rejected():
+    # the reference throws std::out_of_range when it samples such a light (src/shape.cpp:163-165)
+    sd = scenes.soup_scene(10, 16, 16, spp=1)
+    pos, idx = scenes.soup_triangles(4, 3)
+    sd.add_mesh(pos, idx, 0, emission=(1, 1, 1))
+    with pytest.raises(RuntimeError, match="no vertex normals"):
+        hostsim_render(sd, 0, 1, 1)
