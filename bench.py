@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the path-tracing hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json: "Msamples/s ... 1M-tri"; configs[2]): procedural 1M-triangle soup in the 5-wall box with
+one quad light, 1920x1080, 256 samples per pixel per GPU, max_depth 50, no Russian roulette (the reference's
+estimator).  The background is the reference's constant `background_color`: env-map IBL does not exist upstream
+ and is not implemented here.  A "step" is one full render: camera rays -> ... -> framebuffer in HBM
+(-> one RCCL gather of the strips to rank 0 when N > 1).  Scene build/upload happen before the timed region; the
+scene, the path state and the framebuffer are resident in HBM.
+
+Scaling is weak: every GPU renders 1920x1080x256 samples' worth of work — with N GPUs the image keeps its size, the
+rows are sharded in 16-row strips over the ranks and the sample count per pixel is 256*N.
+
+One JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel
+(closest-hit traversal, measured with HIP events inside the timed region) and `cpu_baseline` (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+STATE_BYTES_PER_RAY = 4 + 6 * 4 + 4 * 4  # queue word + origin/direction read + hit record written (f32)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tris", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=256, help="samples per pixel per GPU")
+    ap.add_argument("--max-depth", type=int, default=50)
+    ap.add_argument("--spb", type=int, default=0, help="samples per pixel per batch (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="640x360x1", help="WxHxSPP of the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, sd_full):
+    """Time the CPU path on a bounded sample of the same workload (same scene, fewer pixels / samples).
+    Prefers the compiled reference itself (oracle/_ref/ref_harness, built in the authoring container);
+    otherwise the oracle restatement.  Checker code, used here only as the thing the GPU is compared with."""
+    from take_amd import scenes
+
+    w, h, spp = (int(x) for x in args.cpu_sample.split("x"))
+    cores = os.cpu_count() or 1
+    sd = scenes.soup_scene(args.tris, w, h, spp=spp, max_depth=args.max_depth)
+    samples = w * h * spp
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    sample = f"{args.tris}-tri soup, {w}x{h}, {spp} spp, max_depth {args.max_depth}"
+    if os.path.exists(harness):
+        with tempfile.TemporaryDirectory() as td:
+            xml = scenes.write_reference_inputs(sd, td)
+            r = subprocess.run([harness, "time", xml, str(args.max_depth), str(cores)], stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True, timeout=1500)
+        secs = None
+        for line in r.stdout.splitlines():
+            if "Finish building rendering. Took" in line:  # the reference's own timer, src/render.cpp:83
+                secs = float(line.split("Took")[1].split()[0])
+        if r.returncode == 0 and secs:
+            return {"value": samples / secs / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "reference",
+                    "sample": sample + " (reference render() timer, seed-patched build)"}
+    import oracle
+
+    osc = oracle.OracleScene(sd, precision=1)
+    osc.render(spp, args.max_depth, rng_mode=oracle.RNG_MT_PER_TILE, threads=cores)
+    secs = osc.seconds
+    osc.close()
+    return {"value": samples / secs / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": sample + " (oracle <double, mt19937> tile loop)"}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from take_amd import capi, scenes
+    from take_amd import cdefs as D
+    from take_amd.dist import gather_strips, strip_rows
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    t0 = time.time()
+    spp_total = args.spp * world  # weak scaling: per-GPU samples fixed
+    sd = scenes.soup_scene(args.tris, args.width, args.height, spp=spp_total, max_depth=args.max_depth)
+    scene = capi.Scene(sd, precision=D.TAKE_PRECISION_F32)
+    t_setup = time.time() - t0
+    stats = scene.stats()
+    rows = strip_rows(args.height, rank, world)
+    out = torch.empty((len(rows), args.width, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        scene.render_device(out.data_ptr(), spp_total, args.max_depth, seed=0, strip_first=rank, strip_stride=world,
+                            samples_per_batch=args.spb, stream=stream)
+        return gather_strips(out, args.height, rank, world) if world > 1 else out
+
+    # algorithmic bytes per closest-hit ray: one counting pass (instrumented kernel, never timed), 1 spp
+    scene.set_instrumentation(timing=False, counting=True)
+    scene.render_device(out.data_ptr(), 1, args.max_depth, seed=0, strip_first=rank, strip_stride=world, stream=stream)
+    cc = scene.counters()
+    rays_counted = cc["rays_closest"] + cc["rays_shadow"]
+    bytes_per_ray = ((cc["node_visits"] * cc["node_bytes"] + cc["prim_tests"] * cc["prim_bytes"]) / max(rays_counted, 1)
+                     + STATE_BYTES_PER_RAY)
+    scene.set_instrumentation(timing=True, counting=False)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    acc = {"ms_trace_closest": 0.0, "launches_trace_closest": 0, "rays_closest": 0, "rays_shadow": 0,
+           "ms_trace_shadow": 0.0, "ms_shade": 0.0, "ms_other": 0.0, "ms_total": 0.0, "bounces": 0}
+    img = None
+    for _ in range(args.steps):
+        img = step()
+        c = scene.counters()
+        for k in acc:
+            acc[k] += c[k]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        samples = args.width * args.height * spp_total * args.steps
+        value = samples / elapsed / 1e6
+        # dominant kernel: tk::k_trace<float, false, false> (closest hit).  achieved = algorithmic bytes per launch
+        # / average launch duration, both over the timed region (HIP events recorded on the render stream)
+        n_launch = max(acc["launches_trace_closest"], 1)
+        avg_ms = acc["ms_trace_closest"] / n_launch
+        bytes_per_launch = bytes_per_ray * acc["rays_closest"] / n_launch
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        line = {
+            "metric": "Msamples/s (camera paths/s: rays traced x spp / s), 1M-tri soup",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"procedural {args.tris}-triangle soup in 5-wall box + 1 quad area light, "
+                                   f"{args.width}x{args.height}, {args.spp} spp per GPU ({spp_total} total), max_depth "
+                                   f"{args.max_depth}, no Russian roulette, constant background (no env-map IBL upstream)",
+                       "parallelism": f"tile-row strips over {world} GPU(s), scene replicated, one gather",
+                       "bvh": {"nodes": stats["n_nodes"], "prims": stats["n_prims"], "depth": stats["depth"],
+                               "scene_bytes": stats["device_bytes"]},
+                       "setup_s": t_setup, "rays_per_sample": (acc["rays_closest"] + acc["rays_shadow"]) * world
+                       / max(samples, 1),
+                       "kernel_ms": {k: acc[k] for k in ("ms_trace_closest", "ms_trace_shadow", "ms_shade", "ms_other",
+                                                         "ms_total")}},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "tk::k_trace<float,false,false> (closest hit)", "launches": n_launch,
+                         "avg_launch_ms": avg_ms, "bytes_per_ray": bytes_per_ray,
+                         "rays_per_launch": acc["rays_closest"] / n_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args, sd)
+            except Exception as e:  # the bench line must still come out
+                line["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": os.cpu_count(), "kind": "port",
+                                        "sample": f"failed: {e}"}
+        assert img is not None and torch.isfinite(img).all()
+        print(json.dumps(line), flush=True)
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
