@@ -249,6 +249,13 @@ int take_hip_get_counters(const TakeScene *scene, TakeCounters *out);
  * (bit 0 = event timing, bit 1 = visit counters; both off by default) */
 int take_hip_set_instrumentation(TakeScene *scene, int32_t flags);
 
+/* Test hook: run the device shading functions on the rows of one of the reference's golden tables
+ * (tests/golden/tables, column layouts of oracle/ref_harness.cpp).  kind: 0 material (27 -> 14 columns),
+ * 1 light (30 -> 9), 2 texture (6 -> 3), 3 to_world (6 -> 3), 4 hemisphere_cos (1 -> 4).  `rnd` holds 8 doubles
+ * per row: the first random_real() draws of the mt19937 stream the reference used for that row. */
+int take_hip_debug_table(int32_t kind, int32_t precision, const double *in, int64_t n, int32_t in_cols,
+                         const double *rnd, double *out, int32_t out_cols);
+
 /* BVH introspection (tests / DESIGN figures): node count, primitive count, depth */
 int take_hip_scene_stats(const TakeScene *scene, int64_t *n_nodes, int64_t *n_prims,
                          int32_t *depth, int64_t *device_bytes);

@@ -19,7 +19,7 @@ EXPORTS = [
     "take_hip_last_error", "take_hip_abi_version", "take_hip_device_count", "take_hip_scene_create",
     "take_hip_scene_destroy", "take_hip_render", "take_hip_render_device", "take_hip_render_rows",
     "take_hip_trace_closest", "take_hip_trace_any", "take_hip_trace_closest_device", "take_hip_get_counters",
-    "take_hip_set_instrumentation", "take_hip_scene_stats",
+    "take_hip_set_instrumentation", "take_hip_scene_stats", "take_hip_debug_table",
 ]
 
 
@@ -74,6 +74,23 @@ def _check(rc):
 
 def device_count():
     return _check(lib().take_hip_device_count())
+
+
+DEBUG_TABLES = {"material": (0, 27, 14), "light": (1, 30, 9), "texture": (2, 6, 3), "to_world": (3, 6, 3),
+                "hemicos": (4, 1, 4)}
+
+
+def debug_table(name, inp, rnd, precision=D.TAKE_PRECISION_F64):
+    """Device shading functions on golden-table rows (test hook).  rnd: (n, 8) random_real draws per row."""
+    kind, cin, cout = DEBUG_TABLES[name]
+    inp = np.ascontiguousarray(inp, np.float64).reshape(-1, cin)
+    rnd = np.ascontiguousarray(rnd, np.float64).reshape(-1, 8)
+    n = inp.shape[0]
+    out = np.zeros((n, cout), np.float64)
+    f = lib().take_hip_debug_table
+    f.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+    _check(f(kind, precision, inp.ctypes.data, n, cin, rnd.ctypes.data, out.ctypes.data, cout))
+    return out
 
 
 class Scene:

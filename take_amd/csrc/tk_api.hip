@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -231,6 +232,59 @@ struct Timer {
     }
 };
 
+template <class R> struct ShadeArgs {
+    DeviceScene<R> dev;
+    RenderParams<R> rp;
+    PathState<R> st;
+    const int32_t *queue;
+    const int32_t *n_cur;
+    const int32_t *tag_count;
+    int32_t *next_queue, *n_next, *shadow_queue, *n_shadow;
+    int k;
+    unsigned long long *counters;
+    int grid;
+    hipStream_t stream;
+};
+template <class R, int TAG> void launch_shade_tag(const ShadeArgs<R> &a) {
+    hipLaunchKernelGGL((k_shade<R, TAG>), dim3(a.grid), dim3(BLOCK), 0, a.stream, a.dev, a.rp, a.st, a.queue, a.n_cur,
+                       a.tag_count, a.next_queue, a.n_next, a.shadow_queue, a.n_shadow, a.k, a.counters);
+}
+template <class R> void launch_shade(int tag, const ShadeArgs<R> &a) {
+    switch (tag) {
+        case 0: launch_shade_tag<R, 0>(a); break;
+        case 1: launch_shade_tag<R, 1>(a); break;
+        case 2: launch_shade_tag<R, 2>(a); break;
+        case 3: launch_shade_tag<R, 3>(a); break;
+        case 4: launch_shade_tag<R, 4>(a); break;
+        case 5: launch_shade_tag<R, 5>(a); break;
+        case 6: launch_shade_tag<R, 6>(a); break;
+        case 7: launch_shade_tag<R, 7>(a); break;
+        case 8: launch_shade_tag<R, 8>(a); break;
+        case 9: launch_shade_tag<R, 9>(a); break;
+        case 10: launch_shade_tag<R, 10>(a); break;
+        case 11: launch_shade_tag<R, 11>(a); break;
+        default: launch_shade_tag<R, TAG_MISS>(a); break;
+    }
+}
+
+// Debug aid (TAKE_HIP_DUMP_SLOT=<slot>): print one path's state after every kernel of a round.
+template <class R> void dump_slot(const PathState<R> &st, int64_t slot, const char *tag, int k, hipStream_t stream) {
+    (void)hipStreamSynchronize(stream);
+    std::fprintf(stderr, "[slot %lld] k=%d %s R:", (long long)slot, k, tag);
+    for (int c = 0; c < S_NUM_R; c++) {
+        R v = R(0);
+        (void)hipMemcpy(&v, st.r + (int64_t)c * st.stride + slot, sizeof(R), hipMemcpyDeviceToHost);
+        std::fprintf(stderr, " %.17g", (double)v);
+    }
+    std::fprintf(stderr, " I:");
+    for (int c = 0; c < S_NUM_I; c++) {
+        int32_t v = 0;
+        (void)hipMemcpy(&v, st.i + (int64_t)c * st.stride + slot, sizeof(int32_t), hipMemcpyDeviceToHost);
+        std::fprintf(stderr, " %d", v);
+    }
+    std::fprintf(stderr, "\n");
+}
+
 template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void *d_out, hipStream_t stream) {
     SceneT<R> &sc = pick<R>(ts);
     const int W = sc.host.cam.width, H = sc.host.cam.height;
@@ -265,6 +319,8 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     const bool timing = (ts->instrumentation & 1) != 0;
     const bool counting = (ts->instrumentation & 2) != 0;
     const bool sort_materials = sc.host.n_material_tags > 1;
+    const char *dump_env = std::getenv("TAKE_HIP_DUMP_SLOT");
+    const int64_t dump = dump_env ? std::atoll(dump_env) : -1;
     ts->events.reset();
     ts->timed.clear();
     Timer tm{ts, stream, timing};
@@ -301,6 +357,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
                 hipLaunchKernelGGL((k_trace<R, false, false>), dim3(sc.trace_grid), dim3(BLOCK), 0, stream, sc.dev, st,
                                    sc.queue[cur].p, n_cur, q + Q_HEAD_CLOSEST, rp.ray_eps, sc.counters.p, spill);
             tm.end();
+            if (dump >= 0 && dump < slots) dump_slot(st, dump, "after trace_closest", k, stream);
             const int32_t *shade_in = sc.queue[cur].p;
             if (sort_materials) {
                 tm.begin(TK_OTHER);
@@ -312,9 +369,20 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
                 shade_in = sc.sorted_queue.p;
             }
             tm.begin(TK_SHADE);
-            hipLaunchKernelGGL((k_shade<R>), dim3(wide_grid), dim3(BLOCK), 0, stream, sc.dev, rp, st, shade_in, n_cur,
-                               sc.queue[next].p, n_next, sc.shadow_queue.p, q + Q_N_SHADOW, k, sc.counters.p);
+            {
+                ShadeArgs<R> sa{sc.dev, rp, st, shade_in, n_cur, sort_materials ? tag_count : nullptr, sc.queue[next].p,
+                                n_next, sc.shadow_queue.p, q + Q_N_SHADOW, k, sc.counters.p, wide_grid, stream};
+                if (sort_materials) {
+                    // one specialised launch per material tag present in the scene + the miss segment
+                    for (int t = 0; t < TAKE_MAT_COUNT; t++)
+                        if (sc.host.tag_mask & (1u << t)) launch_shade<R>(t, sa);
+                    launch_shade<R>(TAG_MISS, sa);
+                } else {
+                    launch_shade<R>(sc.host.single_tag, sa);
+                }
+            }
             tm.end();
+            if (dump >= 0 && dump < slots) dump_slot(st, dump, "after shade", k, stream);
             if (k <= o.max_depth) {
                 tm.begin(TK_SHADOW);
                 if (counting)
@@ -326,6 +394,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
                                        st, sc.shadow_queue.p, q + Q_N_SHADOW, q + Q_HEAD_SHADOW, rp.ray_eps,
                                        sc.counters.p, spill);
                 tm.end();
+                if (dump >= 0 && dump < slots) dump_slot(st, dump, "after trace_shadow", k, stream);
             }
             // every 8 rounds look at the queue length: stop launching once every path of the batch has ended
             if ((k & 7) == 7 && k + 1 < rounds) {
@@ -559,6 +628,57 @@ int take_hip_trace_closest_device(TakeScene *ts, const void *d_rays, int64_t n, 
     return ts->precision == TAKE_PRECISION_F64
                ? trace_impl<double>(ts, d_rays, n, d_hits, nullptr, false, count_mode != 0, (hipStream_t)stream)
                : trace_impl<float>(ts, d_rays, n, d_hits, nullptr, false, count_mode != 0, (hipStream_t)stream);
+}
+
+int take_hip_debug_table(int32_t kind, int32_t precision, const double *in, int64_t n, int32_t in_cols,
+                         const double *rnd, double *out, int32_t out_cols) {
+    if (!in || !out || !rnd || n < 0) return fail(TAKE_E_INVALID, "null argument");
+    int nd = check_device();
+    if (nd < 0) return nd;
+    if (n == 0) return TAKE_OK;
+    DevBuf<double> d_in, d_rnd, d_out;
+    DevBuf<ImageInfo> d_img;
+    DevBuf<float> d_texf;
+    DevBuf<double> d_texd;
+    // the fixed 5x4 image the reference harness used for the material / texture tables (oracle/ref_harness.cpp)
+    std::vector<float> tf(60);
+    std::vector<double> td(60);
+    for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 5; x++) {
+            const double c[3] = {0.1 + 0.15 * x + 0.01 * y, 0.9 - 0.2 * y + 0.02 * x, 0.3 + 0.05 * ((x * 3 + y * 7) % 5)};
+            for (int a = 0; a < 3; a++) td[3 * (y * 5 + x) + a] = c[a], tf[3 * (y * 5 + x) + a] = (float)c[a];
+        }
+    std::vector<ImageInfo> img{ImageInfo{5, 4, 0}};
+    int rc = TAKE_OK;
+    do {
+        if (d_in.alloc((size_t)n * in_cols) != hipSuccess || d_rnd.alloc((size_t)n * TAB_RND) != hipSuccess ||
+            d_out.alloc((size_t)n * out_cols) != hipSuccess || d_img.upload(img) != hipSuccess ||
+            d_texf.upload(tf) != hipSuccess || d_texd.upload(td) != hipSuccess) {
+            rc = fail(TAKE_E_NOMEM, "debug table allocation failed");
+            break;
+        }
+        (void)hipMemcpy(d_in.p, in, d_in.bytes(), hipMemcpyHostToDevice);
+        (void)hipMemcpy(d_rnd.p, rnd, d_rnd.bytes(), hipMemcpyHostToDevice);
+        (void)hipMemset(d_out.p, 0, d_out.bytes());
+        const dim3 g((unsigned)((n + BLOCK - 1) / BLOCK)), b(BLOCK);
+        if (precision == TAKE_PRECISION_F64) {
+            DeviceScene<double> sc{};
+            sc.images = d_img.p, sc.texels = d_texd.p;
+            hipLaunchKernelGGL((k_debug_table<double>), g, b, 0, nullptr, sc, kind, d_in.p, d_rnd.p, n, d_out.p);
+        } else {
+            DeviceScene<float> sc{};
+            sc.images = d_img.p, sc.texels = d_texf.p;
+            hipLaunchKernelGGL((k_debug_table<float>), g, b, 0, nullptr, sc, kind, d_in.p, d_rnd.p, n, d_out.p);
+        }
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) {
+            rc = fail(TAKE_E_DEVICE, "debug table kernel failed");
+            break;
+        }
+        if (hipMemcpy(out, d_out.p, d_out.bytes(), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(TAKE_E_DEVICE, "debug table download failed");
+    } while (0);
+    d_in.release(), d_rnd.release(), d_out.release(), d_img.release(), d_texf.release(), d_texd.release();
+    return rc;
 }
 
 int take_hip_get_counters(const TakeScene *ts, TakeCounters *out) {

@@ -142,7 +142,15 @@ TK_HD uint64_t rng_key(uint64_t seed, uint64_t pixel, uint64_t sample) {
 TK_HD uint64_t rng_word(Rng &r) { return rng_mix(r.key + 0x9E3779B97F4A7C15ull * (uint64_t)(r.ctr++)); }
 TK_HD void rng_real(Rng &r, float &out) { out = (float)(rng_word(r) >> 40) * (1.0f / 16777216.0f); }
 TK_HD void rng_real(Rng &r, double &out) { out = (double)(rng_word(r) >> 11) * (1.0 / 9007199254740992.0); }
-template <class R> TK_HD R random_real(Rng &r) {
+// test-hook generator: the draws come from a table (take_hip_debug_table feeds the reference's own mt19937
+// draws to the device functions so that they can be compared with the reference's golden tables)
+struct TableRng {
+    const double *v;
+    uint32_t ctr;
+};
+TK_HD void rng_real(TableRng &r, float &out) { out = (float)r.v[r.ctr++]; }
+TK_HD void rng_real(TableRng &r, double &out) { out = r.v[r.ctr++]; }
+template <class R, class G> TK_HD R random_real(G &r) {
     R v;
     rng_real(r, v);
     return v;

@@ -28,6 +28,8 @@ template <class R> struct HostScene {
     CameraRec<R> cam;
     WideBvhStats stats;
     int n_material_tags = 0;  // distinct material tags in use (1 => the material sort is skipped)
+    uint32_t tag_mask = 0;    // bit t set: some material has tag t
+    int single_tag = 0;       // the tag when n_material_tags == 1
 
     // pointers into the vectors above (a host "device scene" for tests/hostsim; tk_api.hip builds the real one)
     DeviceScene<R> view() const {
@@ -138,7 +140,13 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
         tag_used[m.tag] = true;
     }
     hs.n_material_tags = 0;
-    for (bool b : tag_used) hs.n_material_tags += b ? 1 : 0;
+    hs.tag_mask = 0;
+    for (int t = 0; t < TAKE_MAT_COUNT; t++)
+        if (tag_used[t]) {
+            hs.n_material_tags++;
+            hs.tag_mask |= 1u << t;
+            hs.single_tag = t;
+        }
     hs.images.resize(d.n_images);
     int64_t ntex = 0;
     for (int i = 0; i < d.n_images; i++) {

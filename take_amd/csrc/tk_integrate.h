@@ -76,11 +76,14 @@ TK_HD void generate_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, co
 }
 
 constexpr uint32_t REQ_EXTEND = 1, REQ_SHADOW = 2;
+constexpr int TAG_ANY = -1;    // material tag read from the material record
+constexpr int TAG_MISS = 12;   // the segment of the sorted queue holding the paths whose extend ray missed
 
 // One launch round for one path.  `k` is the shade round (uniform over the launch): k = 0 handles the camera
 // ray's hit, k >= 1 finishes loop iteration k-1; iteration k is started when k <= max_depth.
-// Returns REQ_* bits: which rays this path wants traced next.
-template <class R>
+// TAG: compile-time material tag of the vertex being shaded (see tk_shade.h); a TAG instance may still meet a
+// miss when the queue is not sorted (single-tag scenes).  Returns REQ_* bits: which rays to trace next.
+template <class R, int TAG = TAG_ANY>
 TK_HD uint32_t shade_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, const PathState<R> &st, int64_t slot,
                           int k) {
     const int32_t hit_prim = st.I_(S_HIT, slot);
@@ -90,32 +93,28 @@ TK_HD uint32_t shade_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, c
     Vec3<R> rad{st.R_(S_LX, slot), st.R_(S_LY, slot), st.R_(S_LZ, slot)};
     const Vec3<R> bg = ld3(sc.background);
     const R nlights = R(sc.n_lights);
-    Isect<R> v;
-    bool alive = true;
+    const bool miss = (TAG == TAG_MISS) || hit_prim < 0;
+    Isect<R> v{};
+    bool alive = !miss;
+    if (!miss) make_isect(sc, ro, rd, hit_prim, st.R_(S_HT, slot), st.R_(S_HU, slot), st.R_(S_HV, slot), v);
 
     if (k == 0) {
         // src/integrator/path_tracing.h:7-18
-        if (hit_prim < 0) {
+        if (miss) {
             rad = bg;
-            alive = false;
-        } else {
-            make_isect(sc, ro, rd, hit_prim, st.R_(S_HT, slot), st.R_(S_HU, slot), st.R_(S_HV, slot), v);
-            if (v.area_light != -1) {
-                const LightRec<R> &l = sc.lights[v.area_light];
-                if (l.kind == 1) rad = rad + thr * ld3(l.intensity);
-            }
+        } else if (v.area_light != -1) {
+            const LightRec<R> &l = sc.lights[v.area_light];
+            if (l.kind == 1) rad = rad + thr * ld3(l.intensity);
         }
     } else {
         // second half of loop iteration k-1: src/integrator/path_tracing.h:82-108
         const Vec3<R> FG{st.R_(S_FX, slot), st.R_(S_FY, slot), st.R_(S_FZ, slot)};
         const R pdf = st.R_(S_PDF, slot);
         const bool was_specular = (st.I_(S_FLAGS, slot) & FLAG_SPECULAR) != 0;
-        if (hit_prim < 0) {
+        if (miss) {
             thr = thr * (FG / pdf);
             rad = rad + thr * bg;
-            alive = false;
         } else {
-            make_isect(sc, ro, rd, hit_prim, st.R_(S_HT, slot), st.R_(S_HU, slot), st.R_(S_HV, slot), v);
             Vec3<R> C2{R(0), R(0), R(0)};
             if (v.area_light != -1) {
                 const LightRec<R> &l = sc.lights[v.area_light];
@@ -138,12 +137,14 @@ TK_HD uint32_t shade_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, c
     }
 
     uint32_t req = 0;
-    if (alive && k <= rp.max_depth) {
+    if (TAG != TAG_MISS && alive && k <= rp.max_depth) {
         // first half of loop iteration k: src/integrator/path_tracing.h:22-81
         Rng rng = path_rng(rp, slot, (uint32_t)st.I_(S_CTR, slot));
         const Vec3<R> dir_in = -rd;
         const MaterialRec<R> &m = sc.materials[v.material];
-        const bool is_specular = (m.tag == 2 || m.tag == 1);
+        constexpr int MT = (TAG >= 0 && TAG < TAG_MISS) ? TAG : -1;
+        const int tag = MT >= 0 ? MT : m.tag;
+        const bool is_specular = (tag == 2 || tag == 1);
         if (sc.n_lights > 0 && !is_specular) {
             const int light_id = (int)tk_floor(random_real<R>(rng) * nlights);
             const LightRec<R> &l = sc.lights[light_id];
@@ -156,9 +157,9 @@ TK_HD uint32_t shade_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, c
                 if (light_pdf <= R(0)) {
                     alive = false;  // `break` at :40-43
                 } else {
-                    const R bp = bsdf_pdf(m, dir_in, light_dir, v);
+                    const R bp = bsdf_pdf<R, MT>(m, dir_in, light_dir, v);
                     if (bp > R(0) && !tk_isinf(light_pdf)) {
-                        const Vec3<R> FGl = eval_bsdf(sc, m, dir_in, light_dir, R(0), v);
+                        const Vec3<R> FGl = eval_bsdf<R, MT>(sc, m, dir_in, light_dir, R(0), v);
                         const Vec3<R> C1 = FGl * ld3(l.intensity) * light_pdf / (light_pdf * light_pdf + bp * bp);
                         const Vec3<R> add = thr * C1;
                         st.R_(S_SX, slot) = light_dir.x;
@@ -175,8 +176,8 @@ TK_HD uint32_t shade_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, c
         }
         if (alive) {
             BsdfSample<R> rec;
-            if (sample_bsdf(m, dir_in, v, rng, rec)) {
-                const Vec3<R> FG = eval_bsdf(sc, m, dir_in, rec.dir_out, rec.pdf, v);
+            if (sample_bsdf<R, MT>(m, dir_in, v, rng, rec)) {
+                const Vec3<R> FG = eval_bsdf<R, MT>(sc, m, dir_in, rec.dir_out, rec.pdf, v);
                 const Vec3<R> dir_out = normalize(rec.dir_out);
                 if (rec.pdf > R(0)) {
                     st.R_(S_DX, slot) = dir_out.x;

@@ -134,20 +134,27 @@ k_trace(DeviceScene<R> sc, PathState<R> st, const int32_t *__restrict__ queue, c
 
 // One integrator round.  Requests are compacted into the next extend queue and the shadow queue with one
 // atomic per wave and queue (ballot + mbcnt prefix).
-template <class R>
+// TAG: the kernel is instantiated per material tag (+ TAG_MISS).  With a sorted queue (`tag_count` != null) an
+// instance walks only its tag's segment [sum(tag_count[0..TAG)), +tag_count[TAG]); with an unsorted queue
+// (single-tag scenes) the one instance of the scene's tag walks the whole queue.
+template <class R, int TAG>
 __global__ void __launch_bounds__(BLOCK)
 k_shade(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, const int32_t *__restrict__ queue,
-        const int32_t *__restrict__ n_ptr, int32_t *next_queue, int32_t *n_next, int32_t *shadow_queue,
-        int32_t *n_shadow, int k, unsigned long long *counters) {
-    const int32_t n = *n_ptr;
+        const int32_t *__restrict__ n_ptr, const int32_t *__restrict__ tag_count, int32_t *next_queue,
+        int32_t *n_next, int32_t *shadow_queue, int32_t *n_shadow, int k, unsigned long long *counters) {
+    int32_t begin = 0, n = *n_ptr;
+    if (tag_count) {
+        for (int t = 0; t < TAG; t++) begin += tag_count[t];
+        n = tag_count[TAG];
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[C_BOUNCES], (unsigned long long)n);
     const int32_t n_round = (n + WAVE - 1) / WAVE * WAVE;
     for (int32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += gridDim.x * BLOCK) {
         uint32_t req = 0;
         int32_t slot = 0;
         if (i < n) {
-            slot = queue[i];
-            req = shade_path(sc, rp, st, (int64_t)slot, k);
+            slot = queue[begin + i];
+            req = shade_path<R, TAG>(sc, rp, st, (int64_t)slot, k);
         }
         wave_append((req & REQ_EXTEND) != 0, slot, n_next, next_queue);
         wave_append((req & REQ_SHADOW) != 0, slot, n_shadow, shadow_queue);
@@ -304,4 +311,76 @@ k_trace_rays(DeviceScene<R> sc, const RayAoS<R> *__restrict__ rays, int64_t n, H
     }
 }
 
+}  // namespace tk
+
+// ---- take_hip_debug_table: the device shading functions on the rows of the reference's golden tables
+// (tests/golden/tables; column layouts of oracle/ref_harness.cpp).  `rnd` holds, per row, the first draws of the
+// mt19937 stream the reference used, so sampling can be compared value for value.
+namespace tk {
+enum DebugTable { TAB_MATERIAL = 0, TAB_LIGHT = 1, TAB_TEXTURE = 2, TAB_TO_WORLD = 3, TAB_HEMICOS = 4 };
+constexpr int TAB_RND = 8;
+template <class R>
+__global__ void __launch_bounds__(BLOCK)
+k_debug_table(DeviceScene<R> sc, int kind, const double *__restrict__ in, const double *__restrict__ rnd, int64_t n,
+              double *out) {
+    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n) return;
+    TableRng rng{rnd + TAB_RND * r, 0};
+    auto V = [](const double *p) { return Vec3<R>{R(p[0]), R(p[1]), R(p[2])}; };
+    auto put = [](double *o, Vec3<R> v) { o[0] = (double)v.x, o[1] = (double)v.y, o[2] = (double)v.z; };
+    if (kind == TAB_MATERIAL) {
+        const double *p = in + 27 * r;
+        double *o = out + 14 * r;
+        MaterialRec<R> m{};
+        m.tag = (int)p[0];
+        m.tex_kind = p[22] != 0 ? 1 : 0;
+        m.tex_image = 0;
+        for (int a = 0; a < 3; a++) m.color[a] = R(p[1 + a]);
+        m.uscale = m.tex_kind ? R(p[23]) : R(1), m.vscale = m.tex_kind ? R(p[24]) : R(1);
+        m.uoffset = m.tex_kind ? R(p[25]) : R(0), m.voffset = m.tex_kind ? R(p[26]) : R(0);
+        m.p0 = R(p[4]), m.p1 = R(p[5]);
+        Isect<R> v{};
+        v.gn = V(p + 6), v.sn = V(p + 9);
+        v.uv = {R(p[12]), R(p[13])};
+        const Vec3<R> dir_in = V(p + 14), dir_out = V(p + 17);
+        for (int a = 0; a < 14; a++) o[a] = 0.0;
+        BsdfSample<R> rec;
+        const bool ok = sample_bsdf(m, dir_in, v, rng, rec);
+        o[5] = (double)random_real<R>(rng);
+        if (ok) {
+            o[0] = 1.0;
+            put(o + 1, rec.dir_out);
+            o[4] = (double)rec.pdf;
+            put(o + 6, eval_bsdf(sc, m, dir_in, rec.dir_out, rec.pdf, v));
+            o[13] = (double)bsdf_pdf(m, dir_in, rec.dir_out, v);
+        }
+        o[9] = (double)bsdf_pdf(m, dir_in, dir_out, v);
+        put(o + 10, eval_bsdf(sc, m, dir_in, dir_out, R(p[20]), v));
+    } else if (kind == TAB_LIGHT) {
+        const double *p = in + 30 * r;
+        double *o = out + 9 * r;
+        LightRec<R> l{};
+        l.kind = 1;
+        l.is_sphere = p[0] == 0 ? 1 : 0;
+        for (int a = 0; a < 9; a++) l.v[a] = R(p[1 + a]), l.n[a] = R(p[10 + a]);
+        const Vec3<R> ref = V(p + 19);
+        const LightSample<R> s = sample_light_point(l, ref, rng);
+        put(o, s.pos);
+        put(o + 3, s.n);
+        o[6] = (double)random_real<R>(rng);
+        o[7] = (double)light_pdf_area(l, s.pos, ref);
+        o[8] = (double)light_pdf_area(l, V(p + 24), ref);
+    } else if (kind == TAB_TEXTURE) {
+        const double *p = in + 6 * r;
+        MaterialRec<R> m{};
+        m.tex_kind = 1, m.tex_image = 0;
+        m.uscale = R(p[2]), m.vscale = R(p[3]), m.uoffset = R(p[4]), m.voffset = R(p[5]);
+        put(out + 3 * r, eval_texture(sc, m, Vec2<R>{R(p[0]), R(p[1])}));
+    } else if (kind == TAB_TO_WORLD) {
+        put(out + 3 * r, to_world(V(in + 6 * r), V(in + 6 * r + 3)));
+    } else if (kind == TAB_HEMICOS) {
+        put(out + 4 * r, hemisphere_cos<R>(rng));
+        out[4 * r + 3] = (double)random_real<R>(rng);
+    }
+}
 }  // namespace tk

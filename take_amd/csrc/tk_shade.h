@@ -95,14 +95,14 @@ template <class R> struct BsdfSample {
 template <class R> TK_HD Vec3<R> facing(Vec3<R> dir_in, const Isect<R> &v) {
     return dot(dir_in, v.sn) < R(0) ? -v.sn : v.sn;
 }
-template <class R> TK_HD Vec3<R> hemisphere_cos(Rng &rng) {  // src/material.h:121-132
+template <class R, class G> TK_HD Vec3<R> hemisphere_cos(G &rng) {  // src/material.h:121-132
     R u1 = random_real<R>(rng);
     R u2 = random_real<R>(rng);
     R phi = Const<R>::TWOPI * u2;
     R s = tk_sqrt(tk_clamp(u1, R(0), R(1)));
     return {tk_cos(phi) * s, tk_sin(phi) * s, tk_sqrt(tk_clamp(R(1) - u1, R(0), R(1)))};
 }
-template <class R> TK_HD Vec3<R> power_lobe(R exponent, Rng &rng) {  // src/materials/phong.inl:7-18
+template <class R, class G> TK_HD Vec3<R> power_lobe(R exponent, G &rng) {  // src/materials/phong.inl:7-18
     R u1 = random_real<R>(rng);
     R u2 = random_real<R>(rng);
     R ra1 = R(1) / (exponent + R(1));
@@ -123,12 +123,15 @@ template <class R> TK_HD BsdfSample<R> cosine_sample(Vec3<R> n, const Isect<R> &
     return s;
 }
 
+// TAG: the material tag as a compile-time constant (the shade kernels are instantiated per tag and launched over
+// the tag's segment of the material-sorted queue, so the 12-way dispatch folds away); TAG = -1 reads m.tag.
 // returns false when the reference returns an empty optional (dir_in below the geometric surface)
-template <class R>
-TK_HD bool sample_bsdf(const MaterialRec<R> &m, Vec3<R> dir_in, const Isect<R> &v, Rng &rng, BsdfSample<R> &out) {
+template <class R, int TAG = -1, class G>
+TK_HD bool sample_bsdf(const MaterialRec<R> &m, Vec3<R> dir_in, const Isect<R> &v, G &rng, BsdfSample<R> &out) {
     if (dot(v.gn, dir_in) < R(0)) return false;
     const Vec3<R> n = facing(dir_in, v);
-    switch (m.tag) {
+    const int tag = TAG >= 0 ? TAG : m.tag;
+    switch (tag) {
         case 1: {  // Mirror
             out.dir_out = -dir_in + R(2) * dot(dir_in, n) * n;
             out.pdf = R(1);
@@ -163,7 +166,7 @@ TK_HD bool sample_bsdf(const MaterialRec<R> &m, Vec3<R> dir_in, const Isect<R> &
             if (dot(v.gn, out.dir_out) <= R(0) || dot(h, n) <= R(0) || dot(out.dir_out, h) <= R(0)) {
                 out.pdf = R(0);
             } else {
-                R ndh = m.tag == 4 ? dot(n, h) : tk_clamp(dot(n, h), R(0), R(1));
+                R ndh = tag == 4 ? dot(n, h) : tk_clamp(dot(n, h), R(0), R(1));
                 out.pdf = (m.p0 + R(1)) * R(0.25) * Const<R>::INVTWOPI * tk_pow(ndh, m.p0) / dot(out.dir_out, h);
             }
             return true;
@@ -174,11 +177,13 @@ TK_HD bool sample_bsdf(const MaterialRec<R> &m, Vec3<R> dir_in, const Isect<R> &
     }
 }
 
-template <class R> TK_HD R bsdf_pdf(const MaterialRec<R> &m, Vec3<R> dir_in, Vec3<R> dir_out, const Isect<R> &v) {
-    if (m.tag == 1) return R(0);
+template <class R, int TAG = -1>
+TK_HD R bsdf_pdf(const MaterialRec<R> &m, Vec3<R> dir_in, Vec3<R> dir_out, const Isect<R> &v) {
+    const int tag = TAG >= 0 ? TAG : m.tag;
+    if (tag == 1) return R(0);
     if (dot(v.gn, dir_out) < R(0)) return R(0);
     const Vec3<R> n = facing(dir_in, v);
-    switch (m.tag) {
+    switch (tag) {
         case 2: {
             R F0 = tk_pow((m.p0 - R(1)) / (m.p0 + R(1)), R(2));
             R F = F0 + (R(1) - F0) * tk_pow(R(1) - dot(n, dir_out), R(5));
@@ -202,13 +207,14 @@ template <class R> TK_HD R bsdf_pdf(const MaterialRec<R> &m, Vec3<R> dir_in, Vec
 
 // BSDF * cosine ("FG").  rec_pdf is SampleRecord::pdf: Plastic's specular branch is recognised by pdf == 1
 // (src/materials/plastic.inl:44).
-template <class R>
+template <class R, int TAG = -1>
 TK_HD Vec3<R> eval_bsdf(const DeviceScene<R> &sc, const MaterialRec<R> &m, Vec3<R> dir_in, Vec3<R> dir_out, R rec_pdf,
                         const Isect<R> &v) {
     const Vec3<R> zero{R(0), R(0), R(0)};
     if (dot(v.gn, dir_in) < R(0) || dot(v.gn, dir_out) < R(0)) return zero;
     const Vec3<R> n = facing(dir_in, v);
-    switch (m.tag) {
+    const int tag = TAG >= 0 ? TAG : m.tag;
+    switch (tag) {
         case 1: {
             Vec3<R> F0 = eval_texture(sc, m, v.uv);
             return F0 + one_minus(F0) * tk_pow5(R(1) - dot(n, dir_out));
@@ -269,7 +275,7 @@ TK_HD Vec3<R> eval_bsdf(const DeviceScene<R> &sc, const MaterialRec<R> &m, Vec3<
 template <class R> struct LightSample {
     Vec3<R> pos, n;
 };
-template <class R> TK_HD LightSample<R> sample_light_point(const LightRec<R> &l, Vec3<R> ref, Rng &rng) {
+template <class R, class G> TK_HD LightSample<R> sample_light_point(const LightRec<R> &l, Vec3<R> ref, G &rng) {
     LightSample<R> s;
     R u1 = random_real<R>(rng);
     R u2 = random_real<R>(rng);

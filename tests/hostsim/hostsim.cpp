@@ -6,6 +6,8 @@
 // it with the oracle at small sizes.  It is compiled only by tests/ (tests/hostsim/Makefile), is not part of
 // take_amd/ and is never loaded by the product: libtake_hip.so has no CPU path.
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -33,6 +35,14 @@ struct ArrayStack {
 };
 std::string g_err;
 
+template <class R> void dump_slot(const PathState<R> &st, int64_t slot, const char *tag, int k) {
+    std::fprintf(stderr, "[slot %lld] k=%d %s R:", (long long)slot, k, tag);
+    for (int c = 0; c < S_NUM_R; c++) std::fprintf(stderr, " %.17g", (double)st.R_(c, slot));
+    std::fprintf(stderr, " I:");
+    for (int c = 0; c < S_NUM_I; c++) std::fprintf(stderr, " %d", st.I_(c, slot));
+    std::fprintf(stderr, "\n");
+}
+
 template <class R> int render_t(const TakeSceneDesc &desc, const TakeRenderOpts &o, void *out_v, uint64_t *stats) {
     HostScene<R> hs;
     g_err = prepare_scene<R>(desc, 0, 1, hs);
@@ -57,6 +67,8 @@ template <class R> int render_t(const TakeSceneDesc &desc, const TakeRenderOpts 
     std::vector<R> accum(3 * npix, R(0));
     std::vector<int32_t> q[2], shadow;
     uint64_t n_closest = 0, n_shadow = 0, n_nodes = 0, n_prims = 0, max_stack = 0;
+    const char *dump_env = std::getenv("TAKE_HIP_DUMP_SLOT");
+    const int64_t dump = dump_env ? std::atoll(dump_env) : -1;
     for (int s0 = 0; s0 < o.spp; s0 += spb) {
         const int nb = std::min(spb, o.spp - s0);
         const int64_t n = (int64_t)nb * npix;
@@ -85,11 +97,13 @@ template <class R> int render_t(const TakeSceneDesc &desc, const TakeRenderOpts 
                 st.R_(S_HU, slot) = hit.u;
                 st.R_(S_HV, slot) = hit.v;
             }
+            if (dump >= 0 && dump < slots) dump_slot(st, dump, "after trace_closest", k);
             for (int32_t slot : q[cur]) {  // k_shade
                 uint32_t req = shade_path(sc, rp, st, (int64_t)slot, k);
                 if (req & REQ_EXTEND) q[next].push_back(slot);
                 if (req & REQ_SHADOW) shadow.push_back(slot);
             }
+            if (dump >= 0 && dump < slots) dump_slot(st, dump, "after shade", k);
             for (int32_t slot : shadow) {  // k_trace<shadow>
                 RayT<R> ray = make_ray(st.R_(S_OX, slot), st.R_(S_OY, slot), st.R_(S_OZ, slot), st.R_(S_SX, slot),
                                        st.R_(S_SY, slot), st.R_(S_SZ, slot), rp.ray_eps, st.R_(S_ST, slot));
@@ -104,6 +118,7 @@ template <class R> int render_t(const TakeSceneDesc &desc, const TakeRenderOpts 
                     st.R_(S_LZ, slot) = st.R_(S_LZ, slot) + st.R_(S_CZ, slot);
                 }
             }
+            if (dump >= 0 && dump < slots) dump_slot(st, dump, "after trace_shadow", k);
             if (q[next].empty()) break;
         }
         for (int64_t p = 0; p < npix; p++)  // k_accumulate

@@ -60,16 +60,26 @@ def test_trace_any_equals_occlusion(name):
 
 @pytest.mark.parametrize("name", GOLDEN_SCENES)
 def test_render_f64_matches_oracle(name):
+    """f64 GPU vs oracle<double, counter RNG>.  The only arithmetic difference is ocml vs glibc libm (1 ulp in
+    sin/cos/pow).  Up to 6 bounces that stays at rounding level everywhere: RMSE < 1e-9.  At max_depth 50 a 1-ulp
+    difference in a sampled direction is amplified by every reflection off a curved surface, so a few paths that are
+    still alive after ~40 bounces decorrelate (measured: 2 of 3072 paths in `spherelight`): there the bar is
+    median |diff| < 1e-12, >= 99 % of the pixels within 1e-9, RMSE < 1e-2."""
     sd = golden_scene(name)
     osc = oracle.OracleScene(sd, precision=1)
-    want = osc.render(4, 50, rng_mode=oracle.RNG_COUNTER, seed=11)
-    osc.close()
     sc = capi.Scene(sd, precision=D.TAKE_PRECISION_F64)
-    got = sc.render(spp=4, max_depth=50, seed=11)
-    sc.close()
+    want = osc.render(4, 5, rng_mode=oracle.RNG_COUNTER, seed=11)
+    got = sc.render(spp=4, max_depth=5, seed=11)
     assert got.shape == want.shape
-    assert np.median(np.abs(got - want)) < 1e-12
-    assert rmse(got, want) < 1e-6, rmse(got, want)
+    assert rmse(got, want) < 1e-9, rmse(got, want)
+    want = osc.render(4, 50, rng_mode=oracle.RNG_COUNTER, seed=11)
+    got = sc.render(spp=4, max_depth=50, seed=11)
+    osc.close()
+    sc.close()
+    d = np.abs(got - want).max(axis=2)
+    assert np.median(d) < 1e-12
+    assert (d < 1e-9).mean() >= 0.99, (d < 1e-9).mean()
+    assert rmse(got, want) < 1e-2, rmse(got, want)
 
 
 @pytest.mark.parametrize("name", GOLDEN_SCENES)
