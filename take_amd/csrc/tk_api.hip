@@ -168,10 +168,10 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     HIP_TRY(hipMemset(sc.counters.p, 0, sc.counters.bytes()));
     // persistent trace grid: resident blocks of the heaviest trace kernel x CUs
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<R, false, false>, BLOCK, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_quad<R, false, false, PathIo<R>>, TQ_BLOCK, 0));
     per_cu = std::max(1, std::min(per_cu, 8));
     sc.trace_grid = ts->num_cus * per_cu;
-    HIP_TRY(sc.spill.alloc((size_t)sc.trace_grid * BLOCK * SPILL_STACK));
+    HIP_TRY(sc.spill.alloc((size_t)sc.trace_grid * TQ_QUADS * TQ_SPILL));
     return TAKE_OK;
 }
 
@@ -326,7 +326,10 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     Timer tm{ts, stream, timing};
     int32_t *q = sc.qwords.p;
     int32_t *tag_count = q + Q_NUM_WORDS, *tag_cursor = q + Q_NUM_WORDS + N_SORT_KEYS;
-    StackSpill spill{sc.spill.p, (int64_t)sc.trace_grid * BLOCK};
+    QuadSpill spill{sc.spill.p, (int64_t)sc.trace_grid * TQ_QUADS};
+    const PathIo<R> io_ext0{st, sc.queue[0].p, rp.ray_eps}, io_ext1{st, sc.queue[1].p, rp.ray_eps};
+    const PathIo<R> io_shadow{st, sc.shadow_queue.p, rp.ray_eps};
+    const dim3 tgrid(sc.trace_grid), tblock(TQ_BLOCK);
     const int wide_grid = (int)std::min<int64_t>((slots + BLOCK - 1) / BLOCK, (int64_t)ts->num_cus * 8);
     const int pix_grid = (int)std::min<int64_t>((npix + BLOCK - 1) / BLOCK, (int64_t)ts->num_cus * 8);
 
@@ -351,11 +354,13 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
             hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, stream, q, next);
             tm.begin(TK_CLOSEST);
             if (counting)
-                hipLaunchKernelGGL((k_trace<R, false, true>), dim3(sc.trace_grid), dim3(BLOCK), 0, stream, sc.dev, st,
-                                   sc.queue[cur].p, n_cur, q + Q_HEAD_CLOSEST, rp.ray_eps, sc.counters.p, spill);
+                hipLaunchKernelGGL((k_trace_quad<R, false, true, PathIo<R>>), tgrid, tblock, 0, stream, sc.dev,
+                                   cur ? io_ext1 : io_ext0, n_cur, 0, q + Q_HEAD_CLOSEST, sc.counters.p,
+                                   (int)C_RAYS_CLOSEST, spill);
             else
-                hipLaunchKernelGGL((k_trace<R, false, false>), dim3(sc.trace_grid), dim3(BLOCK), 0, stream, sc.dev, st,
-                                   sc.queue[cur].p, n_cur, q + Q_HEAD_CLOSEST, rp.ray_eps, sc.counters.p, spill);
+                hipLaunchKernelGGL((k_trace_quad<R, false, false, PathIo<R>>), tgrid, tblock, 0, stream, sc.dev,
+                                   cur ? io_ext1 : io_ext0, n_cur, 0, q + Q_HEAD_CLOSEST, sc.counters.p,
+                                   (int)C_RAYS_CLOSEST, spill);
             tm.end();
             if (dump >= 0 && dump < slots) dump_slot(st, dump, "after trace_closest", k, stream);
             const int32_t *shade_in = sc.queue[cur].p;
@@ -386,13 +391,13 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
             if (k <= o.max_depth) {
                 tm.begin(TK_SHADOW);
                 if (counting)
-                    hipLaunchKernelGGL((k_trace<R, true, true>), dim3(sc.trace_grid), dim3(BLOCK), 0, stream, sc.dev,
-                                       st, sc.shadow_queue.p, q + Q_N_SHADOW, q + Q_HEAD_SHADOW, rp.ray_eps,
-                                       sc.counters.p, spill);
+                    hipLaunchKernelGGL((k_trace_quad<R, true, true, PathIo<R>>), tgrid, tblock, 0, stream, sc.dev,
+                                       io_shadow, q + Q_N_SHADOW, 0, q + Q_HEAD_SHADOW, sc.counters.p,
+                                       (int)C_RAYS_SHADOW, spill);
                 else
-                    hipLaunchKernelGGL((k_trace<R, true, false>), dim3(sc.trace_grid), dim3(BLOCK), 0, stream, sc.dev,
-                                       st, sc.shadow_queue.p, q + Q_N_SHADOW, q + Q_HEAD_SHADOW, rp.ray_eps,
-                                       sc.counters.p, spill);
+                    hipLaunchKernelGGL((k_trace_quad<R, true, false, PathIo<R>>), tgrid, tblock, 0, stream, sc.dev,
+                                       io_shadow, q + Q_N_SHADOW, 0, q + Q_HEAD_SHADOW, sc.counters.p,
+                                       (int)C_RAYS_SHADOW, spill);
                 tm.end();
                 if (dump >= 0 && dump < slots) dump_slot(st, dump, "after trace_shadow", k, stream);
             }
@@ -446,7 +451,7 @@ int trace_impl(TakeScene *ts, const void *d_rays, int64_t n, void *d_hits, int32
                hipStream_t stream) {
     SceneT<R> &sc = pick<R>(ts);
     if (n < 0 || n >= ((int64_t)1 << 31) - (1 << 26)) return fail(TAKE_E_INVALID, "ray count out of range");
-    StackSpill spill{sc.spill.p, (int64_t)sc.trace_grid * BLOCK};
+    QuadSpill spill{sc.spill.p, (int64_t)sc.trace_grid * TQ_QUADS};
     int32_t *q = sc.qwords.p;
     HIP_TRY(hipMemsetAsync(q + Q_HEAD_CLOSEST, 0, sizeof(int32_t), stream));
     HIP_TRY(hipMemsetAsync(sc.counters.p, 0, sc.counters.bytes(), stream));
@@ -454,18 +459,17 @@ int trace_impl(TakeScene *ts, const void *d_rays, int64_t n, void *d_hits, int32
     ts->events.reset();
     a = ts->events.get(), b = ts->events.get();
     HIP_TRY(hipEventRecord(a, stream));
-    const RayAoS<R> *rays = (const RayAoS<R> *)d_rays;
-    HitAoS<R> *hits = (HitAoS<R> *)d_hits;
-    const dim3 g(sc.trace_grid), bl(BLOCK);
+    const HookIo<R> io{(const RayAoS<R> *)d_rays, (HitAoS<R> *)d_hits, d_occ};
+    const dim3 g(sc.trace_grid), bl(TQ_BLOCK);
     if (any) {
-        hipLaunchKernelGGL((k_trace_rays<R, true, false>), g, bl, 0, stream, sc.dev, rays, n, hits, d_occ,
-                           q + Q_HEAD_CLOSEST, sc.counters.p, spill);
+        hipLaunchKernelGGL((k_trace_quad<R, true, false, HookIo<R>>), g, bl, 0, stream, sc.dev, io, nullptr, (int32_t)n,
+                           q + Q_HEAD_CLOSEST, sc.counters.p, -1, spill);
     } else if (count) {
-        hipLaunchKernelGGL((k_trace_rays<R, false, true>), g, bl, 0, stream, sc.dev, rays, n, hits, d_occ,
-                           q + Q_HEAD_CLOSEST, sc.counters.p, spill);
+        hipLaunchKernelGGL((k_trace_quad<R, false, true, HookIo<R>>), g, bl, 0, stream, sc.dev, io, nullptr, (int32_t)n,
+                           q + Q_HEAD_CLOSEST, sc.counters.p, -1, spill);
     } else {
-        hipLaunchKernelGGL((k_trace_rays<R, false, false>), g, bl, 0, stream, sc.dev, rays, n, hits, d_occ,
-                           q + Q_HEAD_CLOSEST, sc.counters.p, spill);
+        hipLaunchKernelGGL((k_trace_quad<R, false, false, HookIo<R>>), g, bl, 0, stream, sc.dev, io, nullptr, (int32_t)n,
+                           q + Q_HEAD_CLOSEST, sc.counters.p, -1, spill);
     }
     HIP_TRY(hipEventRecord(b, stream));
     HIP_TRY(hipGetLastError());

@@ -243,23 +243,23 @@ int32_t collapse_to_wide(const std::vector<Bvh2Node> &n2, int root, std::vector<
         }
         Node4<R> node;
         for (int i = 0; i < 4; i++) {
-            node.pad[i] = 0;
+            node.c[i].pad = 0;
             if (i < nk) {
                 const Bvh2Node &c = n2[kids[i]];
                 for (int a = 0; a < 3; a++) {
-                    node.bmin[a][i] = round_down(c.bmin[a], R());
-                    node.bmax[a][i] = round_up(c.bmax[a], R());
+                    node.c[i].bmin[a] = round_down(c.bmin[a], R());
+                    node.c[i].bmax[a] = round_up(c.bmax[a], R());
                 }
                 if (c.count > 0) {
-                    node.child[i] = emit_leaf(c);
+                    node.c[i].child = emit_leaf(c);
                 } else {
-                    node.child[i] = (int32_t)queue.size();
+                    node.c[i].child = (int32_t)queue.size();
                     queue.push_back({kids[i], it.depth + 1});
                     out.emplace_back();
                 }
             } else {
-                for (int a = 0; a < 3; a++) node.bmin[a][i] = Const<R>::inf(), node.bmax[a][i] = -Const<R>::inf();
-                node.child[i] = CHILD_EMPTY;
+                for (int a = 0; a < 3; a++) node.c[i].bmin[a] = Const<R>::inf(), node.c[i].bmax[a] = -Const<R>::inf();
+                node.c[i].child = CHILD_EMPTY;
             }
         }
         out[self] = node;

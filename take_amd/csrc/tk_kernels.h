@@ -9,45 +9,19 @@
 //   k_resolve         divide by spp, vertical flip (src/render.cpp:78)
 //   k_trace_rays      the C-ABI trace hooks: AoS rays in, hit records out
 //
-// Launch shape: the trace kernels are persistent (grid = CUs x resident blocks); each wave pulls 64-ray chunks
-// from a device-side head counter, so a round needs no host read-back of the queue length and expensive rays do
-// not stall a fixed partition.  Traversal stacks live in LDS ([level][thread] int2, conflict-free
-// ds_write_b64/ds_read_b64), with a global spill area behind level LDS_STACK.
+// Launch shape: the trace kernel (tk_trace_quad.h) is persistent (grid = CUs x resident blocks) and pulls work from
+// a device-side head counter, so a round needs no host read-back of the queue length.
 #pragma once
 
 #include <hip/hip_runtime.h>
 
 #include "tk_integrate.h"
+#include "tk_trace_quad.h"
 
 namespace tk {
 
-constexpr int BLOCK = 256;        // 4 waves
-constexpr int LDS_STACK = 16;     // stack levels kept in LDS per lane (8 B each -> 32 KB per block)
-constexpr int SPILL_STACK = 80;   // deeper levels: global memory, per persistent thread
+constexpr int BLOCK = 256;  // 4 waves
 constexpr int WAVE = 64;
-
-struct StackSpill {
-    int2 *base;  // SPILL_STACK entries per thread of the persistent grid, [level][global thread]
-    int64_t stride;
-};
-
-struct LdsStack {
-    int2 *lds;      // &shared[threadIdx.x], level stride BLOCK
-    int2 *spill;    // &spill.base[global thread], level stride spill_stride
-    int64_t spill_stride;
-    __device__ __forceinline__ void push(int level, int32_t child, float key) {
-        int2 e = make_int2(child, __float_as_int(key));
-        if (level < LDS_STACK)
-            lds[level * BLOCK] = e;
-        else
-            spill[(int64_t)(level - LDS_STACK) * spill_stride] = e;
-    }
-    __device__ __forceinline__ void pop(int level, int32_t &child, float &key) {
-        int2 e = (level < LDS_STACK) ? lds[level * BLOCK] : spill[(int64_t)(level - LDS_STACK) * spill_stride];
-        child = e.x;
-        key = __int_as_float(e.y);
-    }
-};
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 // rank of this lane among the set bits of `mask` below it
@@ -71,64 +45,6 @@ k_generate(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, int32_t *queu
     for (int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x; s < n; s += (int64_t)gridDim.x * BLOCK) {
         generate_path(sc, rp, st, s);
         queue[s] = (int32_t)s;
-    }
-}
-
-// Persistent trace kernel.  SHADOW=false: closest hit, writes the hit record.  SHADOW=true: first hit along the
-// shadow segment; an unoccluded path adds its pending throughput*C1 to its radiance (path_tracing.h:53-58).
-template <class R, bool SHADOW, bool COUNT>
-__global__ void __launch_bounds__(BLOCK)
-k_trace(DeviceScene<R> sc, PathState<R> st, const int32_t *__restrict__ queue, const int32_t *__restrict__ n_ptr,
-        int32_t *head, R ray_eps, unsigned long long *counters, StackSpill spill) {
-    __shared__ int2 s_stack[LDS_STACK * BLOCK];
-    LdsStack stack;
-    stack.lds = &s_stack[threadIdx.x];
-    stack.spill = spill.base + ((int64_t)blockIdx.x * BLOCK + threadIdx.x);
-    stack.spill_stride = spill.stride;
-    const int32_t n = *n_ptr;
-    TravCount tc;
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        atomicAdd(&counters[SHADOW ? C_RAYS_SHADOW : C_RAYS_CLOSEST], (unsigned long long)n);
-    for (;;) {
-        int32_t base = 0;
-        if (lane_id() == 0) base = atomicAdd(head, WAVE);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= n) break;
-        const int32_t i = base + lane_id();
-        if (i < n) {
-            const int64_t slot = queue[i];
-            HitT<R> hit;
-            if (!SHADOW) {
-                RayT<R> ray = make_ray(st.R_(S_OX, slot), st.R_(S_OY, slot), st.R_(S_OZ, slot), st.R_(S_DX, slot),
-                                       st.R_(S_DY, slot), st.R_(S_DZ, slot), ray_eps, Const<R>::inf());
-                traverse<R, false, COUNT>(sc, ray, stack, hit, tc);
-                st.I_(S_HIT, slot) = hit.prim;
-                st.R_(S_HT, slot) = hit.t;
-                st.R_(S_HU, slot) = hit.u;
-                st.R_(S_HV, slot) = hit.v;
-            } else {
-                RayT<R> ray = make_ray(st.R_(S_OX, slot), st.R_(S_OY, slot), st.R_(S_OZ, slot), st.R_(S_SX, slot),
-                                       st.R_(S_SY, slot), st.R_(S_SZ, slot), ray_eps, st.R_(S_ST, slot));
-                traverse<R, true, COUNT>(sc, ray, stack, hit, tc);
-                if (hit.prim < 0) {
-                    st.R_(S_LX, slot) = st.R_(S_LX, slot) + st.R_(S_CX, slot);
-                    st.R_(S_LY, slot) = st.R_(S_LY, slot) + st.R_(S_CY, slot);
-                    st.R_(S_LZ, slot) = st.R_(S_LZ, slot) + st.R_(S_CZ, slot);
-                }
-            }
-        }
-    }
-    if (COUNT) {
-        // wave-level reduction, one atomic per wave
-        unsigned long long nn = tc.nodes, pp = tc.prims;
-        for (int off = 32; off > 0; off >>= 1) {
-            nn += __shfl_down(nn, off);
-            pp += __shfl_down(pp, off);
-        }
-        if (lane_id() == 0) {
-            atomicAdd(&counters[C_NODE_VISITS], nn);
-            atomicAdd(&counters[C_PRIM_TESTS], pp);
-        }
     }
 }
 
@@ -249,65 +165,6 @@ k_resolve(const R *__restrict__ accum, R *out, int32_t width, int32_t n_local_ro
         out[o] = accum[3 * (int64_t)p] * inv;
         out[o + 1] = accum[3 * (int64_t)p + 1] * inv;
         out[o + 2] = accum[3 * (int64_t)p + 2] * inv;
-    }
-}
-
-// ---- C-ABI trace hooks: rays as TakeRayF/TakeRayD (8 Reals), hits as TakeHitF / TakeHitD
-template <class R> struct RayAoS {
-    R org[3], tmin, dir[3], tmax;
-};
-template <class R> struct HitAoS;
-template <> struct HitAoS<float> {
-    int32_t shape_id;
-    float t, u, v;
-};
-template <> struct HitAoS<double> {
-    int32_t shape_id, reserved;
-    double t, u, v;
-};
-template <class R, bool ANY, bool COUNT>
-__global__ void __launch_bounds__(BLOCK)
-k_trace_rays(DeviceScene<R> sc, const RayAoS<R> *__restrict__ rays, int64_t n, HitAoS<R> *hits, int32_t *occluded,
-             int32_t *head, unsigned long long *counters, StackSpill spill) {
-    __shared__ int2 s_stack[LDS_STACK * BLOCK];
-    LdsStack stack;
-    stack.lds = &s_stack[threadIdx.x];
-    stack.spill = spill.base + ((int64_t)blockIdx.x * BLOCK + threadIdx.x);
-    stack.spill_stride = spill.stride;
-    TravCount tc;
-    for (;;) {
-        int32_t base = 0;
-        if (lane_id() == 0) base = atomicAdd(head, WAVE);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= n) break;
-        const int64_t i = (int64_t)base + lane_id();
-        if (i < n) {
-            const RayAoS<R> q = rays[i];
-            RayT<R> ray = make_ray(q.org[0], q.org[1], q.org[2], q.dir[0], q.dir[1], q.dir[2], q.tmin, q.tmax);
-            HitT<R> hit;
-            traverse<R, ANY, COUNT>(sc, ray, stack, hit, tc);
-            if (ANY) {
-                occluded[i] = hit.prim >= 0 ? 1 : 0;
-            } else {
-                HitAoS<R> h{};
-                h.shape_id = hit.shape;
-                h.t = hit.prim >= 0 ? hit.t : R(0);
-                h.u = hit.u;
-                h.v = hit.v;
-                hits[i] = h;
-            }
-        }
-    }
-    if (COUNT) {
-        unsigned long long nn = tc.nodes, pp = tc.prims;
-        for (int off = 32; off > 0; off >>= 1) {
-            nn += __shfl_down(nn, off);
-            pp += __shfl_down(pp, off);
-        }
-        if (lane_id() == 0) {
-            atomicAdd(&counters[C_NODE_VISITS], nn);
-            atomicAdd(&counters[C_PRIM_TESTS], pp);
-        }
     }
 }
 

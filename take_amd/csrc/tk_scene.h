@@ -1,9 +1,9 @@
 // tk_scene.h — device-side scene layout (what lives in HBM) and the path-state SoA.
 //
 // Layout rules (DESIGN.md §HBM layout):
-//  * BVH: 4-wide nodes, one 128-byte record per node in f32 (one L2 line): child boxes SoA inside the
-//    node (bmin[axis][4], bmax[axis][4]) + 4 child words.  Nodes are in breadth-first order, so the top
-//    levels are a prefix of the array.
+//  * BVH: 4-wide nodes, one 128-byte record per node in f32 (one L2 line) = four 32-byte child slots
+//    {bmin, bmax, child word}: a traversal quad (4 lanes = 1 ray) reads a node as one coalesced line, one slot
+//    per lane.  Nodes are in breadth-first order, so the top levels are a prefix of the array.
 //  * Primitives are stored in leaf order as pre-transformed records (v0, e1, e2 | centre, radius) so a
 //    leaf is one contiguous run; 48 B in f32.
 //  * Everything the shading stage needs (vertex normals, uvs, materials, lights, texels) is indexed by the
@@ -24,13 +24,18 @@ TK_HD int32_t make_leaf(int32_t first, int32_t count) { return -(1 + first * MAX
 TK_HD int32_t leaf_first(int32_t c) { return (-c - 1) / MAX_LEAF; }
 TK_HD int32_t leaf_count(int32_t c) { return ((-c - 1) % MAX_LEAF) + 1; }
 
-template <class R> struct alignas(16) Node4 {
-    R bmin[3][4];
-    R bmax[3][4];
-    int32_t child[4];
-    int32_t pad[4];  // f32: 96 + 16 + 16 = 128 B
+// One child slot of a wide node: box + child word.  32 B in f32: the four lanes of a traversal quad each load one
+// slot (2 x dwordx4), i.e. one wave instruction reads whole 128-B lines, 4 lanes per line.
+template <class R> struct alignas(16) NodeChild {
+    R bmin[3];
+    R bmax[3];
+    int32_t child;
+    int32_t pad;
 };
-static_assert(sizeof(Node4<float>) == 128, "one L2 line per f32 node");
+template <class R> struct alignas(16) Node4 {
+    NodeChild<R> c[4];
+};
+static_assert(sizeof(NodeChild<float>) == 32 && sizeof(Node4<float>) == 128, "one L2 line per f32 node");
 
 constexpr int32_t PRIM_TRIANGLE = 0;
 constexpr int32_t PRIM_SPHERE = 1;

@@ -85,6 +85,19 @@ TK_HD float stack_key(double t) {  // largest float <= t: keeps pop-time culling
     return f;
 }
 
+// Conservative slab test of one child slot: true when [tmin, tbest] can overlap the box.  Both planes are widened
+// by a few ulp (t >= tmin > 0 on this path, so the scaling is monotone), which keeps closest-hit results
+// independent of the tree shape.  tn = entry distance (the traversal order key).
+template <class R>
+TK_HD bool box_test(const NodeChild<R> &c, Vec3<R> o, R idx, R idy, R idz, R tmin, R tbest, R &tn) {
+    R t0x = (c.bmin[0] - o.x) * idx, t1x = (c.bmax[0] - o.x) * idx;
+    R t0y = (c.bmin[1] - o.y) * idy, t1y = (c.bmax[1] - o.y) * idy;
+    R t0z = (c.bmin[2] - o.z) * idz, t1z = (c.bmax[2] - o.z) * idz;
+    tn = tk_fmax(tk_fmax(tk_fmin(t0x, t1x), tk_fmin(t0y, t1y)), tk_fmax(tk_fmin(t0z, t1z), tmin));
+    R tf = tk_fmin(tk_fmin(tk_fmax(t0x, t1x), tk_fmax(t0y, t1y)), tk_fmin(tk_fmax(t0z, t1z), tbest));
+    return (tn * Const<R>::BOX_SHRINK <= tf * Const<R>::BOX_GROW) && (c.child != CHILD_EMPTY);
+}
+
 struct TravCount {
     uint32_t nodes = 0, prims = 0;
 };
@@ -109,15 +122,10 @@ TK_HD void traverse(const DeviceScene<R> &sc, const RayT<R> &ray, Stack &stack, 
             int32_t ch[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                R t0x = (n.bmin[0][i] - ray.o.x) * idx, t1x = (n.bmax[0][i] - ray.o.x) * idx;
-                R t0y = (n.bmin[1][i] - ray.o.y) * idy, t1y = (n.bmax[1][i] - ray.o.y) * idy;
-                R t0z = (n.bmin[2][i] - ray.o.z) * idz, t1z = (n.bmax[2][i] - ray.o.z) * idz;
-                R tn = tk_fmax(tk_fmax(tk_fmin(t0x, t1x), tk_fmin(t0y, t1y)), tk_fmax(tk_fmin(t0z, t1z), ray.tmin));
-                R tf = tk_fmin(tk_fmin(tk_fmax(t0x, t1x), tk_fmax(t0y, t1y)), tk_fmin(tk_fmax(t0z, t1z), tbest));
-                // widen by a few ulp on both sides (t >= tmin > 0 on the path, so scaling is monotone)
-                bool ok = (tn * Const<R>::BOX_SHRINK <= tf * Const<R>::BOX_GROW) && (n.child[i] != CHILD_EMPTY);
+                R tn;
+                bool ok = box_test(n.c[i], ray.o, idx, idy, idz, ray.tmin, tbest, tn);
                 key[i] = ok ? tn : Const<R>::inf();
-                ch[i] = n.child[i];
+                ch[i] = n.c[i].child;
             }
             // sorting network, ascending by entry distance
 #define TK_CSWAP(a, b)                        \
