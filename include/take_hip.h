@@ -210,6 +210,10 @@ typedef struct TakeCounters {
     uint64_t launches_trace_shadow;
     uint64_t node_bytes;     /* bytes of one interior-node fetch in this layout   */
     uint64_t prim_bytes;     /* bytes of one primitive record                     */
+    uint64_t leaf_visits;    /* leaves fetched (counting mode)                    */
+    uint64_t wave_node_steps;/* wave-level node-phase iterations (counting mode): node_visits / (16 * this) is
+                                the fraction of the 16 ray slots of a wave doing useful work in a node step */
+    uint64_t wave_leaf_steps;/* wave-level leaf-phase iterations (counting mode)  */
 } TakeCounters;
 
 const char *take_hip_last_error(void);

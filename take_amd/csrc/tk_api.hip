@@ -95,7 +95,7 @@ template <class R> struct SceneT {
     DevBuf<R> accum, out;
     DevBuf<int32_t> qwords;  // Q_NUM_WORDS + 2 * N_SORT_KEYS
     DevBuf<unsigned long long> counters;
-    DevBuf<int2> spill;
+    DevBuf<unsigned long long> spill;
     int64_t capacity = 0;  // path slots allocated
     int trace_grid = 0;
 
@@ -135,7 +135,9 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     SceneT<R> &sc = pick<R>(ts);
     int threads = opts.bvh_threads > 0 ? opts.bvh_threads : (int)std::thread::hardware_concurrency();
     if (threads <= 0) threads = 1;
-    std::string err = prepare_scene<R>(desc, opts.max_leaf_size, threads, sc.host);
+    int max_leaf = opts.max_leaf_size;
+    if (max_leaf <= 0 && std::getenv("TAKE_HIP_MAX_LEAF")) max_leaf = std::atoi(std::getenv("TAKE_HIP_MAX_LEAF"));  // tuning knob
+    std::string err = prepare_scene<R>(desc, max_leaf, threads, sc.host);
     if (!err.empty()) return fail(TAKE_E_INVALID, err);
     const HostScene<R> &h = sc.host;
     HIP_TRY(sc.nodes.upload(h.nodes));
@@ -429,6 +431,9 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     tc.node_visits = c[C_NODE_VISITS];
     tc.prim_tests = c[C_PRIM_TESTS];
     tc.bounces = c[C_BOUNCES];
+    tc.leaf_visits = c[C_LEAF_VISITS];
+    tc.wave_node_steps = c[C_WAVE_NODE_STEPS];
+    tc.wave_leaf_steps = c[C_WAVE_LEAF_STEPS];
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
     tc.ms_total = ms;
@@ -482,6 +487,9 @@ int trace_impl(TakeScene *ts, const void *d_rays, int64_t n, void *d_hits, int32
     (any ? ts->counters.rays_shadow : ts->counters.rays_closest) = (uint64_t)n;
     ts->counters.node_visits = c[C_NODE_VISITS];
     ts->counters.prim_tests = c[C_PRIM_TESTS];
+    ts->counters.leaf_visits = c[C_LEAF_VISITS];
+    ts->counters.wave_node_steps = c[C_WAVE_NODE_STEPS];
+    ts->counters.wave_leaf_steps = c[C_WAVE_LEAF_STEPS];
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, a, b));
     (any ? ts->counters.ms_trace_shadow : ts->counters.ms_trace_closest) = ms;

@@ -23,11 +23,15 @@ namespace tk {
 
 constexpr int TQ_BLOCK = 256;                 // 4 waves = 64 quads
 constexpr int TQ_QUADS = TQ_BLOCK / 4;
-constexpr int TQ_LEVELS = 28;                 // per-quad stack levels in LDS
+constexpr int TQ_LEVELS = 32;                 // per-quad stack levels in LDS (8 B each: 17 KB per block)
 constexpr int TQ_STRIDE = TQ_QUADS + 4;       // level stride in entries: 544 B = 32 (mod 128) -> conflict-free quads
-constexpr int TQ_SPILL = 72;                  // deeper levels in global memory (per quad)
-constexpr int TQ_STEPS = 6;                   // traversal steps between refill checks
+constexpr int TQ_SPILL = 68;                  // deeper levels in global memory (per quad); builder caps depth at 96
+constexpr int TQ_NODE_ITERS = 12;             // at most this many node steps before the next leaf phase / refill check
+constexpr int TQ_NODE_MIN_QUADS = 6;          // leave the node phase when fewer quads than this are at interior nodes
 constexpr int TQ_REFILL_MIN = 4;              // refill when at least this many of the 16 quads are idle
+constexpr uint32_t TQ_KEY_INVALID = 0xFFFFFFFFu;
+
+typedef unsigned long long tq_entry;          // low word: child word, high word: order key (float bits | lane)
 
 // ---- quad cross-lane helpers (DPP quad_perm: no LDS traffic)
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v) {
@@ -53,9 +57,13 @@ __device__ __forceinline__ int quad_max_i(int v) {
 }
 
 struct QuadSpill {
-    int2 *base;      // [level][global quad]
+    tq_entry *base;  // [level][global quad]
     int64_t stride;  // quads in the persistent grid
 };
+// The overflow path of the stack is kept out of line so that the common path compiles to plain ds_write_b64 /
+// ds_read_b64 (a pointer select between LDS and global memory turns every access into a flat_* instruction).
+__device__ __noinline__ void tq_spill_store(tq_entry *p, tq_entry e) { *p = e; }
+__device__ __noinline__ tq_entry tq_spill_load(const tq_entry *p) { return *p; }
 
 // IO policies: where rays come from and where results go.
 //   count(), load(i, ray, tag): ray i of the work list;  store_*(tag, ...): called by ONE lane of the quad.
@@ -123,25 +131,16 @@ template <class R, bool ANY_HIT, bool COUNT, class Io>
 __global__ void __launch_bounds__(TQ_BLOCK)
 k_trace_quad(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_t n_direct, int32_t *head,
              unsigned long long *counters, int counter_word, QuadSpill spill) {
-    __shared__ int2 s_stack[TQ_LEVELS * TQ_STRIDE];
+    __shared__ tq_entry s_stack[TQ_LEVELS * TQ_STRIDE];
     const int lane = threadIdx.x & 63;
     const int ql = lane & 3;
-    int2 *const stk = s_stack + (threadIdx.x >> 2);
-    int2 *const spl = spill.base + ((int64_t)blockIdx.x * TQ_QUADS + (threadIdx.x >> 2));
+    const int quad = threadIdx.x >> 2;
+    tq_entry *const spl = spill.base + ((int64_t)blockIdx.x * TQ_QUADS + quad);
     const int32_t n = n_ptr ? *n_ptr : n_direct;
     if (blockIdx.x == 0 && threadIdx.x == 0 && counter_word >= 0)
         atomicAdd(&counters[counter_word], (unsigned long long)n);
-
-    auto push = [&](int level, int32_t child, float key) {
-        const int2 e = make_int2(child, __float_as_int(key));
-        if (level < TQ_LEVELS)
-            stk[level * TQ_STRIDE] = e;
-        else
-            spl[(int64_t)(level - TQ_LEVELS) * spill.stride] = e;
-    };
-    auto pop = [&](int level) -> int2 {
-        return level < TQ_LEVELS ? stk[level * TQ_STRIDE] : spl[(int64_t)(level - TQ_LEVELS) * spill.stride];
-    };
+    const char *const node_base = (const char *)sc.nodes;
+    const char *const prim_base = (const char *)sc.prims;
 
     // wave-local pool of queue indices [pool_next, pool_end), refilled 64 at a time
     int32_t pool_next = 0, pool_end = 0;
@@ -156,14 +155,45 @@ k_trace_quad(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_
     // per-lane best candidate (differs between the lanes of a quad)
     R my_t = Const<R>::inf(), my_u = R(0), my_v = R(0);
     int32_t my_prim = -1, my_shape = -1;
-    uint32_t cnt_nodes = 0, cnt_prims = 0;
+    uint32_t cnt_nodes = 0, cnt_prims = 0, cnt_leaves = 0, cnt_wnode = 0, cnt_wleaf = 0;
+
+    // Next subtree that can still hold a closer hit (entries whose entry distance is beyond the closest hit are
+    // dropped).  Returns true when the stack is empty: the ray is finished.
+    auto advance = [&]() -> bool {
+        for (;;) {
+            if (sp == 0) return true;
+            --sp;
+            const tq_entry e = (sp < TQ_LEVELS) ? s_stack[sp * TQ_STRIDE + quad]
+                                                : tq_spill_load(spl + (int64_t)(sp - TQ_LEVELS) * spill.stride);
+            cur = (int32_t)(uint32_t)e;
+            const float key = __uint_as_float((uint32_t)(e >> 32) & ~3u);
+            if ((R)key <= tbest) return false;
+        }
+    };
+    // ONE lane of the quad writes the result
+    auto finish = [&]() {
+        if (ANY_HIT) {
+            const bool occ = quad_max_i(my_prim) >= 0;
+            if (ql == 0) io.store_occlusion(tag, occ);
+        } else {
+            // the lane holding the closest candidate writes it (highest lane on an exact tie)
+            const int win = quad_max_i((my_prim >= 0 && my_t == tbest) ? ql : -1);
+            if (win < 0) {
+                if (ql == 0) io.store_hit(tag, -1, -1, ray.tmax, R(0), R(0));
+            } else if (ql == win) {
+                io.store_hit(tag, my_prim, my_shape, my_t, my_u, my_v);
+            }
+        }
+        active = false;
+    };
 
     for (;;) {
         // ------------------------------------------------------------------ refill idle quads from the pool
         {
             const uint64_t idle0 = __ballot(!active);
             const int n_idle = (int)(__popcll(idle0) >> 2);
-            if (n_idle >= TQ_REFILL_MIN || n_idle == 16) {
+            if (n_idle >= TQ_REFILL_MIN) {
+#pragma unroll 1
                 for (int pass = 0; pass < 2; ++pass) {
                     const uint64_t idle = __ballot(!active);
                     if (idle == 0) break;
@@ -202,83 +232,88 @@ k_trace_quad(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_
             if (exhausted) break;
             continue;
         }
-        // ------------------------------------------------------------------ a few traversal steps
-        for (int step = 0; step < TQ_STEPS; ++step) {
-            if (active) {
-                bool finished = false;
-                if (cur >= 0) {
-                    // interior node: one child slot per lane
-                    const NodeChild<R> c = sc.nodes[cur].c[ql];
-                    if (COUNT && ql == 0) cnt_nodes++;
-                    R tn;
-                    const bool ok = box_test(c, ray.o, idx, idy, idz, ray.tmin, tbest, tn);
-                    const R key = ok ? tn : Const<R>::inf();
-                    const R k0 = dpp_f<QP_B0>(key), k1 = dpp_f<QP_B1>(key), k2 = dpp_f<QP_B2>(key), k3 = dpp_f<QP_B3>(key);
-                    // rank of this lane's child among the four by (entry distance, lane)
-                    const int rank = (int)(k0 < key || (k0 == key && 0 < ql)) + (int)(k1 < key || (k1 == key && 1 < ql)) +
-                                     (int)(k2 < key || (k2 == key && 2 < ql)) + (int)(k3 < key || (k3 == key && 3 < ql));
-                    const int nhit = (int)(k0 < Const<R>::inf()) + (int)(k1 < Const<R>::inf()) +
-                                     (int)(k2 < Const<R>::inf()) + (int)(k3 < Const<R>::inf());
-                    // far-to-near: the nearest child ends on top of the stack and is popped right below
-                    if (ok) push(sp + nhit - 1 - rank, c.child, stack_key(key));
-                    sp += nhit;
-                } else if (cur != CHILD_EMPTY) {
-                    // leaf: one primitive per lane
-                    const int first = leaf_first(cur), cnt = leaf_count(cur);
-                    if (COUNT && ql == 0) cnt_prims += (uint32_t)cnt;
-                    if (ql < cnt) {
-                        const PrimRec<R> p = sc.prims[first + ql];
-                        R t, u = R(0), v = R(0);
-                        const bool ok = ((p.meta & 0xff) == PRIM_TRIANGLE) ? tri_test(p.a, ray, tbest, t, u, v)
-                                                                           : sphere_test(p.a, ray, tbest, t);
-                        if (ok) {
-                            my_t = t, my_u = u, my_v = v;
-                            my_prim = first + ql;
-                            my_shape = p.shape_id;
-                        }
-                    }
-                    tbest = tk_fmin(tbest, quad_min(my_t));
-                    if (ANY_HIT) finished = quad_max_i(my_prim) >= 0;
+        // ------------------------------------------------------------------ node phase
+        // Interior-node steps only; a quad that reaches a leaf waits.  The leaf code (triangle / sphere tests) is
+        // ~2x the node code, and with one ray per quad some quad of the wave is at a leaf in almost every step:
+        // running the two in separate phases keeps the leaf code out of the node steps.
+#pragma unroll 1
+        for (int it = 0; it < TQ_NODE_ITERS; ++it) {
+            const bool at_node = active && cur >= 0;
+            const int n_node = (int)__popcll(__ballot(at_node));
+            if (n_node == 0) break;
+            // few quads left at interior nodes and some waiting at a leaf: switch to the leaf phase
+            if (n_node < 4 * TQ_NODE_MIN_QUADS && __ballot(active && cur < 0) != 0) break;
+            if (COUNT && lane == 0) cnt_wnode++;
+            if (at_node) {
+                // one child slot per lane: 32-bit byte offset from the (scalar) node base
+                const uint32_t off = (uint32_t)cur * (uint32_t)sizeof(Node4<R>) + (uint32_t)ql * (uint32_t)sizeof(NodeChild<R>);
+                const NodeChild<R> c = *(const NodeChild<R> *)(node_base + off);
+                if (COUNT && ql == 0) cnt_nodes++;
+                R tn;
+                const bool ok = box_test(c, ray.o, idx, idy, idz, ray.tmin, tbest, tn);
+                // order key: the (shrunk, hence conservative) entry distance as an integer — non-negative floats
+                // order like their bit patterns — with the lane in the two low bits to make the four keys distinct
+                const uint32_t key =
+                    ok ? ((__float_as_uint(stack_key(tn * Const<R>::BOX_SHRINK)) & ~3u) | (uint32_t)ql) : TQ_KEY_INVALID;
+                const uint32_t k0 = (uint32_t)dpp_i<QP_B0>((int)key), k1 = (uint32_t)dpp_i<QP_B1>((int)key);
+                const uint32_t k2 = (uint32_t)dpp_i<QP_B2>((int)key), k3 = (uint32_t)dpp_i<QP_B3>((int)key);
+                const int rank = (int)(k0 < key) + (int)(k1 < key) + (int)(k2 < key) + (int)(k3 < key);
+                const int nhit = (int)(k0 != TQ_KEY_INVALID) + (int)(k1 != TQ_KEY_INVALID) + (int)(k2 != TQ_KEY_INVALID) +
+                                 (int)(k3 != TQ_KEY_INVALID);
+                // far-to-near: the nearest child ends on top of the stack and is popped right below
+                if (ok) {
+                    const int level = sp + nhit - 1 - rank;
+                    const tq_entry e = ((tq_entry)key << 32) | (tq_entry)(uint32_t)c.child;
+                    if (level < TQ_LEVELS)
+                        s_stack[level * TQ_STRIDE + quad] = e;
+                    else
+                        tq_spill_store(spl + (int64_t)(level - TQ_LEVELS) * spill.stride, e);
                 }
-                // next subtree that can still hold a closer hit
-                if (!finished) {
-                    for (;;) {
-                        if (sp == 0) {
-                            finished = true;
-                            break;
-                        }
-                        const int2 e = pop(--sp);
-                        cur = e.x;
-                        if ((R)__int_as_float(e.y) <= tbest) break;
+                sp += nhit;
+                if (advance()) finish();
+            }
+        }
+        // ------------------------------------------------------------------ leaf phase: one primitive per lane
+        {
+            const bool at_leaf = active && cur < 0 && cur != CHILD_EMPTY;
+            if (COUNT && lane == 0 && __ballot(at_leaf) != 0) cnt_wleaf++;
+            if (at_leaf) {
+                const int first = leaf_first(cur), cnt = leaf_count(cur);
+                if (COUNT && ql == 0) cnt_prims += (uint32_t)cnt, cnt_leaves++;
+                if (ql < cnt) {
+                    const uint32_t off = (uint32_t)(first + ql) * (uint32_t)sizeof(PrimRec<R>);
+                    const PrimRec<R> p = *(const PrimRec<R> *)(prim_base + off);
+                    R t, u = R(0), v = R(0);
+                    const bool ok = ((p.meta & 0xff) == PRIM_TRIANGLE) ? tri_test(p.a, ray, tbest, t, u, v)
+                                                                       : sphere_test(p.a, ray, tbest, t);
+                    if (ok) {
+                        my_t = t, my_u = u, my_v = v;
+                        my_prim = first + ql;
+                        my_shape = p.shape_id;
                     }
                 }
-                if (finished) {
-                    if (ANY_HIT) {
-                        const bool occ = quad_max_i(my_prim) >= 0;
-                        if (ql == 0) io.store_occlusion(tag, occ);
-                    } else {
-                        // the lane holding the closest candidate writes it (highest lane on an exact tie)
-                        const int win = quad_max_i((my_prim >= 0 && my_t == tbest) ? ql : -1);
-                        if (win < 0) {
-                            if (ql == 0) io.store_hit(tag, -1, -1, ray.tmax, R(0), R(0));
-                        } else if (ql == win) {
-                            io.store_hit(tag, my_prim, my_shape, my_t, my_u, my_v);
-                        }
-                    }
-                    active = false;
-                }
+                tbest = tk_fmin(tbest, quad_min(my_t));
+                bool finished = ANY_HIT ? (quad_max_i(my_prim) >= 0) : false;
+                if (!finished) finished = advance();
+                if (finished) finish();
+            } else if (active && cur == CHILD_EMPTY) {
+                if (advance()) finish();  // empty scene: nothing to test
             }
         }
     }
     if (COUNT) {
-        unsigned long long nn = cnt_nodes, pp = cnt_prims;
+        unsigned long long nn = cnt_nodes, pp = cnt_prims, ll = cnt_leaves;
         for (int off = 32; off > 0; off >>= 1) {
             nn += __shfl_down(nn, off);
             pp += __shfl_down(pp, off);
+            ll += __shfl_down(ll, off);
         }
         if (lane == 0) {
             atomicAdd(&counters[C_NODE_VISITS], nn);
             atomicAdd(&counters[C_PRIM_TESTS], pp);
+            atomicAdd(&counters[C_LEAF_VISITS], ll);
+            atomicAdd(&counters[C_WAVE_NODE_STEPS], (unsigned long long)cnt_wnode);
+            atomicAdd(&counters[C_WAVE_LEAF_STEPS], (unsigned long long)cnt_wleaf);
         }
     }
 }

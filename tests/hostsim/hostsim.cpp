@@ -45,7 +45,7 @@ template <class R> void dump_slot(const PathState<R> &st, int64_t slot, const ch
 
 template <class R> int render_t(const TakeSceneDesc &desc, const TakeRenderOpts &o, void *out_v, uint64_t *stats) {
     HostScene<R> hs;
-    g_err = prepare_scene<R>(desc, 0, 1, hs);
+    g_err = prepare_scene<R>(desc, std::getenv("HOSTSIM_MAX_LEAF") ? std::atoi(std::getenv("HOSTSIM_MAX_LEAF")) : 0, 1, hs);
     if (!g_err.empty()) return TAKE_E_INVALID;
     DeviceScene<R> sc = hs.view();
     const int W = hs.cam.width, H = hs.cam.height;
@@ -145,7 +145,7 @@ template <class R> int render_t(const TakeSceneDesc &desc, const TakeRenderOpts 
 
 template <class R> int trace_t(const TakeSceneDesc &desc, const void *rays_v, int64_t n, void *hits_v, int any) {
     HostScene<R> hs;
-    g_err = prepare_scene<R>(desc, 0, 1, hs);
+    g_err = prepare_scene<R>(desc, std::getenv("HOSTSIM_MAX_LEAF") ? std::atoi(std::getenv("HOSTSIM_MAX_LEAF")) : 0, 1, hs);
     if (!g_err.empty()) return TAKE_E_INVALID;
     DeviceScene<R> sc = hs.view();
     const R *rays = (const R *)rays_v;  // org3 tmin dir3 tmax
