@@ -98,6 +98,8 @@ template <class R> struct SceneT {
     DevBuf<unsigned long long> spill;
     int64_t capacity = 0;  // path slots allocated
     int trace_grid = 0;
+    int group = 4;             // lanes per ray of the trace kernel
+    int64_t spill_stride = 0;  // ray groups in the persistent trace grid
 
     size_t scene_bytes() const {
         return nodes.bytes() + prims.bytes() + shapes.bytes() + meshes.bytes() + face_idx.bytes() + normals.bytes() +
@@ -170,10 +172,24 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     HIP_TRY(hipMemset(sc.counters.p, 0, sc.counters.bytes()));
     // persistent trace grid: resident blocks of the heaviest trace kernel x CUs
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_quad<R, false, false, PathIo<R>>, TQ_BLOCK, 0));
+    sc.group = 4;
+    if (const char *g = std::getenv("TAKE_HIP_GROUP")) sc.group = std::atoi(g);  // tuning knob: lanes per ray (1, 2, 4)
+    if (sc.group != 1 && sc.group != 2) sc.group = 4;
+    int groups_per_block = 0, spill_levels = 0;
+    if (sc.group == 4) {
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 4, false, false, PathIo<R>>, TQ_BLOCK, 0));
+        groups_per_block = GroupGeom<4>::GROUPS, spill_levels = GroupGeom<4>::SPILL;
+    } else if (sc.group == 2) {
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>>, TQ_BLOCK, 0));
+        groups_per_block = GroupGeom<2>::GROUPS, spill_levels = GroupGeom<2>::SPILL;
+    } else {
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 1, false, false, PathIo<R>>, TQ_BLOCK, 0));
+        groups_per_block = GroupGeom<1>::GROUPS, spill_levels = GroupGeom<1>::SPILL;
+    }
     per_cu = std::max(1, std::min(per_cu, 8));
     sc.trace_grid = ts->num_cus * per_cu;
-    HIP_TRY(sc.spill.alloc((size_t)sc.trace_grid * TQ_QUADS * TQ_SPILL));
+    sc.spill_stride = (int64_t)sc.trace_grid * groups_per_block;
+    HIP_TRY(sc.spill.alloc((size_t)sc.spill_stride * spill_levels));
     return TAKE_OK;
 }
 
@@ -233,6 +249,28 @@ struct Timer {
         (void)hipEventRecord(ts->timed.back().second.second, stream);
     }
 };
+
+// launch the trace kernel instance for (lanes per ray, any-hit, counting)
+template <class R, class Io>
+void launch_trace(int group, bool any, bool count, dim3 grid, hipStream_t stream, const DeviceScene<R> &dev, const Io &io,
+                  const int32_t *n_ptr, int32_t n_direct, int32_t *head, unsigned long long *counters, int counter_word,
+                  QuadSpill spill) {
+#define TK_LAUNCH(G, A, C)                                                                                           \
+    hipLaunchKernelGGL((k_trace_group<R, G, A, C, Io>), grid, dim3(TQ_BLOCK), 0, stream, dev, io, n_ptr, n_direct, head, \
+                       counters, counter_word, spill)
+#define TK_LAUNCH_G(G)                     \
+    do {                                   \
+        if (any && count) TK_LAUNCH(G, true, true);        \
+        else if (any) TK_LAUNCH(G, true, false);           \
+        else if (count) TK_LAUNCH(G, false, true);         \
+        else TK_LAUNCH(G, false, false);                   \
+    } while (0)
+    if (group == 4) TK_LAUNCH_G(4);
+    else if (group == 2) TK_LAUNCH_G(2);
+    else TK_LAUNCH_G(1);
+#undef TK_LAUNCH_G
+#undef TK_LAUNCH
+}
 
 template <class R> struct ShadeArgs {
     DeviceScene<R> dev;
@@ -328,10 +366,10 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     Timer tm{ts, stream, timing};
     int32_t *q = sc.qwords.p;
     int32_t *tag_count = q + Q_NUM_WORDS, *tag_cursor = q + Q_NUM_WORDS + N_SORT_KEYS;
-    QuadSpill spill{sc.spill.p, (int64_t)sc.trace_grid * TQ_QUADS};
+    QuadSpill spill{sc.spill.p, sc.spill_stride};
     const PathIo<R> io_ext0{st, sc.queue[0].p, rp.ray_eps}, io_ext1{st, sc.queue[1].p, rp.ray_eps};
     const PathIo<R> io_shadow{st, sc.shadow_queue.p, rp.ray_eps};
-    const dim3 tgrid(sc.trace_grid), tblock(TQ_BLOCK);
+    const dim3 tgrid(sc.trace_grid);
     const int wide_grid = (int)std::min<int64_t>((slots + BLOCK - 1) / BLOCK, (int64_t)ts->num_cus * 8);
     const int pix_grid = (int)std::min<int64_t>((npix + BLOCK - 1) / BLOCK, (int64_t)ts->num_cus * 8);
 
@@ -355,14 +393,8 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
             int32_t *n_cur = q + (cur ? Q_N_EXT1 : Q_N_EXT0), *n_next = q + (next ? Q_N_EXT1 : Q_N_EXT0);
             hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, stream, q, next);
             tm.begin(TK_CLOSEST);
-            if (counting)
-                hipLaunchKernelGGL((k_trace_quad<R, false, true, PathIo<R>>), tgrid, tblock, 0, stream, sc.dev,
-                                   cur ? io_ext1 : io_ext0, n_cur, 0, q + Q_HEAD_CLOSEST, sc.counters.p,
-                                   (int)C_RAYS_CLOSEST, spill);
-            else
-                hipLaunchKernelGGL((k_trace_quad<R, false, false, PathIo<R>>), tgrid, tblock, 0, stream, sc.dev,
-                                   cur ? io_ext1 : io_ext0, n_cur, 0, q + Q_HEAD_CLOSEST, sc.counters.p,
-                                   (int)C_RAYS_CLOSEST, spill);
+            launch_trace<R>(sc.group, false, counting, tgrid, stream, sc.dev, cur ? io_ext1 : io_ext0, n_cur, 0,
+                            q + Q_HEAD_CLOSEST, sc.counters.p, (int)C_RAYS_CLOSEST, spill);
             tm.end();
             if (dump >= 0 && dump < slots) dump_slot(st, dump, "after trace_closest", k, stream);
             const int32_t *shade_in = sc.queue[cur].p;
@@ -392,14 +424,8 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
             if (dump >= 0 && dump < slots) dump_slot(st, dump, "after shade", k, stream);
             if (k <= o.max_depth) {
                 tm.begin(TK_SHADOW);
-                if (counting)
-                    hipLaunchKernelGGL((k_trace_quad<R, true, true, PathIo<R>>), tgrid, tblock, 0, stream, sc.dev,
-                                       io_shadow, q + Q_N_SHADOW, 0, q + Q_HEAD_SHADOW, sc.counters.p,
-                                       (int)C_RAYS_SHADOW, spill);
-                else
-                    hipLaunchKernelGGL((k_trace_quad<R, true, false, PathIo<R>>), tgrid, tblock, 0, stream, sc.dev,
-                                       io_shadow, q + Q_N_SHADOW, 0, q + Q_HEAD_SHADOW, sc.counters.p,
-                                       (int)C_RAYS_SHADOW, spill);
+                launch_trace<R>(sc.group, true, counting, tgrid, stream, sc.dev, io_shadow, q + Q_N_SHADOW, 0,
+                                q + Q_HEAD_SHADOW, sc.counters.p, (int)C_RAYS_SHADOW, spill);
                 tm.end();
                 if (dump >= 0 && dump < slots) dump_slot(st, dump, "after trace_shadow", k, stream);
             }
@@ -456,7 +482,7 @@ int trace_impl(TakeScene *ts, const void *d_rays, int64_t n, void *d_hits, int32
                hipStream_t stream) {
     SceneT<R> &sc = pick<R>(ts);
     if (n < 0 || n >= ((int64_t)1 << 31) - (1 << 26)) return fail(TAKE_E_INVALID, "ray count out of range");
-    QuadSpill spill{sc.spill.p, (int64_t)sc.trace_grid * TQ_QUADS};
+    QuadSpill spill{sc.spill.p, sc.spill_stride};
     int32_t *q = sc.qwords.p;
     HIP_TRY(hipMemsetAsync(q + Q_HEAD_CLOSEST, 0, sizeof(int32_t), stream));
     HIP_TRY(hipMemsetAsync(sc.counters.p, 0, sc.counters.bytes(), stream));
@@ -465,17 +491,8 @@ int trace_impl(TakeScene *ts, const void *d_rays, int64_t n, void *d_hits, int32
     a = ts->events.get(), b = ts->events.get();
     HIP_TRY(hipEventRecord(a, stream));
     const HookIo<R> io{(const RayAoS<R> *)d_rays, (HitAoS<R> *)d_hits, d_occ};
-    const dim3 g(sc.trace_grid), bl(TQ_BLOCK);
-    if (any) {
-        hipLaunchKernelGGL((k_trace_quad<R, true, false, HookIo<R>>), g, bl, 0, stream, sc.dev, io, nullptr, (int32_t)n,
-                           q + Q_HEAD_CLOSEST, sc.counters.p, -1, spill);
-    } else if (count) {
-        hipLaunchKernelGGL((k_trace_quad<R, false, true, HookIo<R>>), g, bl, 0, stream, sc.dev, io, nullptr, (int32_t)n,
-                           q + Q_HEAD_CLOSEST, sc.counters.p, -1, spill);
-    } else {
-        hipLaunchKernelGGL((k_trace_quad<R, false, false, HookIo<R>>), g, bl, 0, stream, sc.dev, io, nullptr, (int32_t)n,
-                           q + Q_HEAD_CLOSEST, sc.counters.p, -1, spill);
-    }
+    launch_trace<R>(sc.group, any, count, dim3(sc.trace_grid), stream, sc.dev, io, nullptr, (int32_t)n, q + Q_HEAD_CLOSEST,
+                    sc.counters.p, -1, spill);
     HIP_TRY(hipEventRecord(b, stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));

@@ -127,15 +127,40 @@ template <class R> struct HookIo {  // the C-ABI trace hooks: AoS rays in, hit r
     __device__ __forceinline__ void store_occlusion(int64_t i, bool occ) const { occluded[i] = occ ? 1 : 0; }
 };
 
-template <class R, bool ANY_HIT, bool COUNT, class Io>
+// Geometry of a ray group: G lanes cooperate on one ray (G = 4: quad, one child slot per lane; G = 2: pair, two
+// slots per lane; G = 1: one ray per lane, four slots per lane).  More lanes per ray = better coalescing and less
+// divergence, fewer lanes per ray = fewer instructions per box test (the per-step overhead is shared by more boxes).
+template <int G> struct GroupGeom {
+    static constexpr int LOG2 = G == 4 ? 2 : (G == 2 ? 1 : 0);
+    static constexpr int CPL = 4 / G;                    // child slots per lane
+    static constexpr int GROUPS = TQ_BLOCK / G;          // rays in flight per block
+    static constexpr int PER_WAVE = 64 / G;
+    static constexpr int LEVELS = G == 4 ? 32 : (G == 2 ? 24 : 16);  // stack levels in LDS
+    static constexpr int STRIDE = GROUPS + 4;            // entries per level (+4: 32 B skew between levels)
+    static constexpr int SPILL = 100 - LEVELS;           // deeper levels in global memory; builder caps depth at 96
+};
+template <int G, class T> __device__ __forceinline__ T group_min(T v) {
+    if (G >= 2) v = tk_fmin(v, dpp_f<QP_X1>(v));
+    if (G >= 4) v = tk_fmin(v, dpp_f<QP_X2>(v));
+    return v;
+}
+template <int G> __device__ __forceinline__ int group_max_i(int v) {
+    if (G >= 2) v = max(v, dpp_i<QP_X1>(v));
+    if (G >= 4) v = max(v, dpp_i<QP_X2>(v));
+    return v;
+}
+
+template <class R, int G, bool ANY_HIT, bool COUNT, class Io>
 __global__ void __launch_bounds__(TQ_BLOCK)
-k_trace_quad(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_t n_direct, int32_t *head,
-             unsigned long long *counters, int counter_word, QuadSpill spill) {
-    __shared__ tq_entry s_stack[TQ_LEVELS * TQ_STRIDE];
+k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_t n_direct, int32_t *head,
+              unsigned long long *counters, int counter_word, QuadSpill spill) {
+    using GG = GroupGeom<G>;
+    constexpr int CPL = GG::CPL;
+    __shared__ tq_entry s_stack[GG::LEVELS * GG::STRIDE];
     const int lane = threadIdx.x & 63;
-    const int ql = lane & 3;
-    const int quad = threadIdx.x >> 2;
-    tq_entry *const spl = spill.base + ((int64_t)blockIdx.x * TQ_QUADS + quad);
+    const int gl = lane & (G - 1);            // lane within the group
+    const int grp = threadIdx.x >> GG::LOG2;  // group within the block
+    tq_entry *const spl = spill.base + ((int64_t)blockIdx.x * GG::GROUPS + grp);
     const int32_t n = n_ptr ? *n_ptr : n_direct;
     if (blockIdx.x == 0 && threadIdx.x == 0 && counter_word >= 0)
         atomicAdd(&counters[counter_word], (unsigned long long)n);
@@ -145,14 +170,14 @@ k_trace_quad(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_
     // wave-local pool of queue indices [pool_next, pool_end), refilled 64 at a time
     int32_t pool_next = 0, pool_end = 0;
     bool exhausted = false;
-    // per-quad traversal state (identical in the 4 lanes unless noted)
+    // per-group traversal state (identical in the G lanes unless noted)
     bool active = false;
     RayT<R> ray{};
     R idx = R(0), idy = R(0), idz = R(0), tbest = R(0);
     int64_t tag = 0;
     int sp = 0;
     int32_t cur = CHILD_EMPTY;
-    // per-lane best candidate (differs between the lanes of a quad)
+    // per-lane best candidate (differs between the lanes of a group)
     R my_t = Const<R>::inf(), my_u = R(0), my_v = R(0);
     int32_t my_prim = -1, my_shape = -1;
     uint32_t cnt_nodes = 0, cnt_prims = 0, cnt_leaves = 0, cnt_wnode = 0, cnt_wleaf = 0;
@@ -163,24 +188,24 @@ k_trace_quad(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_
         for (;;) {
             if (sp == 0) return true;
             --sp;
-            const tq_entry e = (sp < TQ_LEVELS) ? s_stack[sp * TQ_STRIDE + quad]
-                                                : tq_spill_load(spl + (int64_t)(sp - TQ_LEVELS) * spill.stride);
+            const tq_entry e = (sp < GG::LEVELS) ? s_stack[sp * GG::STRIDE + grp]
+                                                 : tq_spill_load(spl + (int64_t)(sp - GG::LEVELS) * spill.stride);
             cur = (int32_t)(uint32_t)e;
             const float key = __uint_as_float((uint32_t)(e >> 32) & ~3u);
             if ((R)key <= tbest) return false;
         }
     };
-    // ONE lane of the quad writes the result
+    // ONE lane of the group writes the result
     auto finish = [&]() {
         if (ANY_HIT) {
-            const bool occ = quad_max_i(my_prim) >= 0;
-            if (ql == 0) io.store_occlusion(tag, occ);
+            const bool occ = group_max_i<G>(my_prim) >= 0;
+            if (gl == 0) io.store_occlusion(tag, occ);
         } else {
             // the lane holding the closest candidate writes it (highest lane on an exact tie)
-            const int win = quad_max_i((my_prim >= 0 && my_t == tbest) ? ql : -1);
+            const int win = group_max_i<G>((my_prim >= 0 && my_t == tbest) ? gl : -1);
             if (win < 0) {
-                if (ql == 0) io.store_hit(tag, -1, -1, ray.tmax, R(0), R(0));
-            } else if (ql == win) {
+                if (gl == 0) io.store_hit(tag, -1, -1, ray.tmax, R(0), R(0));
+            } else if (gl == win) {
                 io.store_hit(tag, my_prim, my_shape, my_t, my_u, my_v);
             }
         }
@@ -188,11 +213,11 @@ k_trace_quad(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_
     };
 
     for (;;) {
-        // ------------------------------------------------------------------ refill idle quads from the pool
+        // ------------------------------------------------------------------ refill idle groups from the pool
         {
             const uint64_t idle0 = __ballot(!active);
-            const int n_idle = (int)(__popcll(idle0) >> 2);
-            if (n_idle >= TQ_REFILL_MIN) {
+            const int n_idle = (int)(__popcll(idle0) >> GG::LOG2);
+            if (n_idle * 4 >= GG::PER_WAVE) {  // at least a quarter of the wave's ray slots are idle
 #pragma unroll 1
                 for (int pass = 0; pass < 2; ++pass) {
                     const uint64_t idle = __ballot(!active);
@@ -211,7 +236,7 @@ k_trace_quad(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_
                         pool_end = min(base + 64, n);
                         avail = pool_end - pool_next;
                     }
-                    const int my_rank = (int)(__popcll(idle & ((1ull << (lane & ~3)) - 1ull)) >> 2);
+                    const int my_rank = (int)(__popcll(idle & ((1ull << (lane & ~(G - 1))) - 1ull)) >> GG::LOG2);
                     if (!active && my_rank < avail) {
                         io.template load<ANY_HIT>(pool_next + my_rank, ray, tag);
                         idx = safe_inv(ray.d.x), idy = safe_inv(ray.d.y), idz = safe_inv(ray.d.z);
@@ -224,7 +249,7 @@ k_trace_quad(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_
                         my_u = my_v = R(0);
                         active = true;
                     }
-                    pool_next += min(avail, (int32_t)(__popcll(idle) >> 2));
+                    pool_next += min(avail, (int32_t)(__popcll(idle) >> GG::LOG2));
                 }
             }
         }
@@ -233,67 +258,100 @@ k_trace_quad(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_
             continue;
         }
         // ------------------------------------------------------------------ node phase
-        // Interior-node steps only; a quad that reaches a leaf waits.  The leaf code (triangle / sphere tests) is
-        // ~2x the node code, and with one ray per quad some quad of the wave is at a leaf in almost every step:
-        // running the two in separate phases keeps the leaf code out of the node steps.
+        // Interior-node steps only; a group that reaches a leaf waits.  The leaf code (triangle / sphere tests) is
+        // ~2x the node code, and some group of the wave is at a leaf in almost every step: running the two in
+        // separate phases keeps the leaf code out of the node steps.
 #pragma unroll 1
         for (int it = 0; it < TQ_NODE_ITERS; ++it) {
             const bool at_node = active && cur >= 0;
             const int n_node = (int)__popcll(__ballot(at_node));
             if (n_node == 0) break;
-            // few quads left at interior nodes and some waiting at a leaf: switch to the leaf phase
-            if (n_node < 4 * TQ_NODE_MIN_QUADS && __ballot(active && cur < 0) != 0) break;
+            // few groups left at interior nodes and some waiting at a leaf: switch to the leaf phase
+            if (n_node * 8 < 3 * 64 && __ballot(active && cur < 0) != 0) break;
             if (COUNT && lane == 0) cnt_wnode++;
             if (at_node) {
-                // one child slot per lane: 32-bit byte offset from the (scalar) node base
-                const uint32_t off = (uint32_t)cur * (uint32_t)sizeof(Node4<R>) + (uint32_t)ql * (uint32_t)sizeof(NodeChild<R>);
-                const NodeChild<R> c = *(const NodeChild<R> *)(node_base + off);
-                if (COUNT && ql == 0) cnt_nodes++;
-                R tn;
-                const bool ok = box_test(c, ray.o, idx, idy, idz, ray.tmin, tbest, tn);
-                // order key: the (shrunk, hence conservative) entry distance as an integer — non-negative floats
-                // order like their bit patterns — with the lane in the two low bits to make the four keys distinct
-                const uint32_t key =
-                    ok ? ((__float_as_uint(stack_key(tn * Const<R>::BOX_SHRINK)) & ~3u) | (uint32_t)ql) : TQ_KEY_INVALID;
-                const uint32_t k0 = (uint32_t)dpp_i<QP_B0>((int)key), k1 = (uint32_t)dpp_i<QP_B1>((int)key);
-                const uint32_t k2 = (uint32_t)dpp_i<QP_B2>((int)key), k3 = (uint32_t)dpp_i<QP_B3>((int)key);
-                const int rank = (int)(k0 < key) + (int)(k1 < key) + (int)(k2 < key) + (int)(k3 < key);
-                const int nhit = (int)(k0 != TQ_KEY_INVALID) + (int)(k1 != TQ_KEY_INVALID) + (int)(k2 != TQ_KEY_INVALID) +
-                                 (int)(k3 != TQ_KEY_INVALID);
+                // CPL child slots per lane: 32-bit byte offset from the (scalar) node base
+                if (COUNT && gl == 0) cnt_nodes++;
+                const uint32_t off = (uint32_t)cur * (uint32_t)sizeof(Node4<R>) +
+                                     (uint32_t)(gl * CPL) * (uint32_t)sizeof(NodeChild<R>);
+                uint32_t key[CPL];
+                int32_t child[CPL];
+#pragma unroll
+                for (int j = 0; j < CPL; j++) {
+                    const NodeChild<R> c = *(const NodeChild<R> *)(node_base + off + j * (uint32_t)sizeof(NodeChild<R>));
+                    R tn;
+                    const bool ok = box_test(c, ray.o, idx, idy, idz, ray.tmin, tbest, tn);
+                    // order key: the (shrunk, hence conservative) entry distance as an integer — non-negative
+                    // floats order like their bit patterns — with the slot number in the two low bits, which makes
+                    // the four keys of a node distinct
+                    key[j] = ok ? ((__float_as_uint(stack_key(tn * Const<R>::BOX_SHRINK)) & ~3u) | (uint32_t)(gl * CPL + j))
+                                : TQ_KEY_INVALID;
+                    child[j] = c.child;
+                }
+                // rank of each of my slots among the four keys of the node (keys of the other lanes come by DPP;
+                // a key never compares less than itself, so broadcasting all four is fine)
+                int rank[CPL], nhit = 0;
+                if (G == 4) {
+                    const uint32_t k0 = (uint32_t)dpp_i<QP_B0>((int)key[0]), k1 = (uint32_t)dpp_i<QP_B1>((int)key[0]);
+                    const uint32_t k2 = (uint32_t)dpp_i<QP_B2>((int)key[0]), k3 = (uint32_t)dpp_i<QP_B3>((int)key[0]);
+                    rank[0] = (int)(k0 < key[0]) + (int)(k1 < key[0]) + (int)(k2 < key[0]) + (int)(k3 < key[0]);
+                    nhit = (int)(k0 != TQ_KEY_INVALID) + (int)(k1 != TQ_KEY_INVALID) + (int)(k2 != TQ_KEY_INVALID) +
+                           (int)(k3 != TQ_KEY_INVALID);
+                } else if (G == 2) {
+                    const uint32_t p0 = (uint32_t)dpp_i<QP_X1>((int)key[0]), p1 = (uint32_t)dpp_i<QP_X1>((int)key[CPL - 1]);
+                    rank[0] = (int)(key[CPL - 1] < key[0]) + (int)(p0 < key[0]) + (int)(p1 < key[0]);
+                    rank[CPL - 1] = (int)(key[0] < key[CPL - 1]) + (int)(p0 < key[CPL - 1]) + (int)(p1 < key[CPL - 1]);
+                    nhit = (int)(key[0] != TQ_KEY_INVALID) + (int)(key[CPL - 1] != TQ_KEY_INVALID) +
+                           (int)(p0 != TQ_KEY_INVALID) + (int)(p1 != TQ_KEY_INVALID);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CPL; j++) {
+                        rank[j] = 0;
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) rank[j] += (int)(key[i] < key[j]);
+                        nhit += (int)(key[j] != TQ_KEY_INVALID);
+                    }
+                }
                 // far-to-near: the nearest child ends on top of the stack and is popped right below
-                if (ok) {
-                    const int level = sp + nhit - 1 - rank;
-                    const tq_entry e = ((tq_entry)key << 32) | (tq_entry)(uint32_t)c.child;
-                    if (level < TQ_LEVELS)
-                        s_stack[level * TQ_STRIDE + quad] = e;
-                    else
-                        tq_spill_store(spl + (int64_t)(level - TQ_LEVELS) * spill.stride, e);
+#pragma unroll
+                for (int j = 0; j < CPL; j++) {
+                    if (key[j] != TQ_KEY_INVALID) {
+                        const int level = sp + nhit - 1 - rank[j];
+                        const tq_entry e = ((tq_entry)key[j] << 32) | (tq_entry)(uint32_t)child[j];
+                        if (level < GG::LEVELS)
+                            s_stack[level * GG::STRIDE + grp] = e;
+                        else
+                            tq_spill_store(spl + (int64_t)(level - GG::LEVELS) * spill.stride, e);
+                    }
                 }
                 sp += nhit;
                 if (advance()) finish();
             }
         }
-        // ------------------------------------------------------------------ leaf phase: one primitive per lane
+        // ------------------------------------------------------------------ leaf phase: primitives dealt to the lanes
         {
             const bool at_leaf = active && cur < 0 && cur != CHILD_EMPTY;
             if (COUNT && lane == 0 && __ballot(at_leaf) != 0) cnt_wleaf++;
             if (at_leaf) {
                 const int first = leaf_first(cur), cnt = leaf_count(cur);
-                if (COUNT && ql == 0) cnt_prims += (uint32_t)cnt, cnt_leaves++;
-                if (ql < cnt) {
-                    const uint32_t off = (uint32_t)(first + ql) * (uint32_t)sizeof(PrimRec<R>);
+                if (COUNT && gl == 0) cnt_prims += (uint32_t)cnt, cnt_leaves++;
+#pragma unroll 1
+                for (int k = gl; k < cnt; k += G) {
+                    const uint32_t off = (uint32_t)(first + k) * (uint32_t)sizeof(PrimRec<R>);
                     const PrimRec<R> p = *(const PrimRec<R> *)(prim_base + off);
                     R t, u = R(0), v = R(0);
-                    const bool ok = ((p.meta & 0xff) == PRIM_TRIANGLE) ? tri_test(p.a, ray, tbest, t, u, v)
-                                                                       : sphere_test(p.a, ray, tbest, t);
+                    // later primitives of this lane see the distance of its earlier hits (<= keeps the last on a tie)
+                    const R tlim = tk_fmin(tbest, my_t);
+                    const bool ok = ((p.meta & 0xff) == PRIM_TRIANGLE) ? tri_test(p.a, ray, tlim, t, u, v)
+                                                                       : sphere_test(p.a, ray, tlim, t);
                     if (ok) {
                         my_t = t, my_u = u, my_v = v;
-                        my_prim = first + ql;
+                        my_prim = first + k;
                         my_shape = p.shape_id;
                     }
                 }
-                tbest = tk_fmin(tbest, quad_min(my_t));
-                bool finished = ANY_HIT ? (quad_max_i(my_prim) >= 0) : false;
+                tbest = tk_fmin(tbest, group_min<G>(my_t));
+                bool finished = ANY_HIT ? (group_max_i<G>(my_prim) >= 0) : false;
                 if (!finished) finished = advance();
                 if (finished) finish();
             } else if (active && cur == CHILD_EMPTY) {

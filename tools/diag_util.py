@@ -1,8 +1,12 @@
-"""diagnostic: traversal work counters of one counting-mode render (quad utilisation of the trace kernel)"""
-import sys, os
+"""diagnostic: traversal work counters of one counting-mode render (ray-slot utilisation of the trace kernel)"""
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from take_amd import capi, scenes
+
+PW = 64 // int(os.environ.get("TAKE_HIP_GROUP", "4"))  # ray slots per wave
 tris = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 sd = scenes.soup_scene(tris, 1920, 1080, spp=1)
 sc = capi.Scene(sd)
@@ -10,7 +14,11 @@ sc.set_instrumentation(timing=True, counting=True)
 sc.render(spp=1, max_depth=50, seed=0)
 c = sc.counters()
 rays = c["rays_closest"] + c["rays_shadow"]
-print({k: c[k] for k in ("rays_closest", "rays_shadow", "node_visits", "leaf_visits", "prim_tests", "wave_node_steps", "wave_leaf_steps")})
-print(f"nodes/ray {c['node_visits']/rays:.1f} leaves/ray {c['leaf_visits']/rays:.1f} prims/ray {c['prim_tests']/rays:.1f}")
-print(f"node-phase quad utilisation {c['node_visits']/(16*c['wave_node_steps']):.3f}  leaf-phase {c['leaf_visits']/(16*c['wave_leaf_steps']):.3f}")
-print(f"wave steps per ray: node {c['wave_node_steps']*16/rays:.1f} leaf {c['wave_leaf_steps']*16/rays:.1f}")
+print({k: c[k] for k in ("rays_closest", "rays_shadow", "node_visits", "leaf_visits", "prim_tests", "wave_node_steps",
+                         "wave_leaf_steps")})
+print("nodes/ray %.1f leaves/ray %.1f prims/ray %.1f" % (c["node_visits"] / rays, c["leaf_visits"] / rays,
+                                                        c["prim_tests"] / rays))
+print("node-phase utilisation %.3f  leaf-phase %.3f" % (c["node_visits"] / (PW * c["wave_node_steps"]),
+                                                       c["leaf_visits"] / (PW * c["wave_leaf_steps"])))
+print("wave steps per ray: node %.1f leaf %.1f   ms closest %.1f shadow %.1f" % (
+    c["wave_node_steps"] * PW / rays, c["wave_leaf_steps"] * PW / rays, c["ms_trace_closest"], c["ms_trace_shadow"]))
