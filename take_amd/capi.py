@@ -12,7 +12,7 @@ import numpy as np
 from . import cdefs as D
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libtake_hip.so")
+LIB_PATH = os.environ.get("TAKE_HIP_LIB") or os.path.join(_PKG, "libtake_hip.so")  # TAKE_HIP_LIB: tuning builds
 _LIB = None
 
 EXPORTS = [

@@ -90,7 +90,6 @@ template <class R> struct SceneT {
     DeviceScene<R> dev{};
     // render workspace (grown on demand)
     DevBuf<R> state_r;
-    DevBuf<int32_t> state_i;
     DevBuf<int32_t> queue[2], shadow_queue, sorted_queue;
     DevBuf<R> accum, out;
     DevBuf<int32_t> qwords;  // Q_NUM_WORDS + 2 * N_SORT_KEYS
@@ -108,7 +107,7 @@ template <class R> struct SceneT {
     void release() {
         nodes.release(), prims.release(), shapes.release(), meshes.release(), face_idx.release();
         normals.release(), uvs.release(), texels.release(), materials.release(), images.release(), lights.release();
-        state_r.release(), state_i.release(), queue[0].release(), queue[1].release(), shadow_queue.release();
+        state_r.release(), queue[0].release(), queue[1].release(), shadow_queue.release();
         sorted_queue.release(), accum.release(), out.release(), qwords.release(), counters.release(), spill.release();
     }
 };
@@ -172,9 +171,9 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     HIP_TRY(hipMemset(sc.counters.p, 0, sc.counters.bytes()));
     // persistent trace grid: resident blocks of the heaviest trace kernel x CUs
     int per_cu = 0;
-    sc.group = 4;
+    sc.group = 2;  // pair traversal: measured fastest on MI355X (profiles/)
     if (const char *g = std::getenv("TAKE_HIP_GROUP")) sc.group = std::atoi(g);  // tuning knob: lanes per ray (1, 2, 4)
-    if (sc.group != 1 && sc.group != 2) sc.group = 4;
+    if (sc.group != 1 && sc.group != 4) sc.group = 2;
     int groups_per_block = 0, spill_levels = 0;
     if (sc.group == 4) {
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 4, false, false, PathIo<R>>, TQ_BLOCK, 0));
@@ -195,8 +194,7 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
 
 template <class R> int ensure_workspace(SceneT<R> &sc, int64_t slots, int64_t npix) {
     if (slots > sc.capacity) {
-        HIP_TRY(sc.state_r.alloc((size_t)S_NUM_R * slots));
-        HIP_TRY(sc.state_i.alloc((size_t)S_NUM_I * slots));
+        HIP_TRY(sc.state_r.alloc((size_t)PATH_REC * slots));
         HIP_TRY(sc.queue[0].alloc(slots));
         HIP_TRY(sc.queue[1].alloc(slots));
         HIP_TRY(sc.shadow_queue.alloc(slots));
@@ -311,17 +309,12 @@ template <class R> void launch_shade(int tag, const ShadeArgs<R> &a) {
 template <class R> void dump_slot(const PathState<R> &st, int64_t slot, const char *tag, int k, hipStream_t stream) {
     (void)hipStreamSynchronize(stream);
     std::fprintf(stderr, "[slot %lld] k=%d %s R:", (long long)slot, k, tag);
-    for (int c = 0; c < S_NUM_R; c++) {
-        R v = R(0);
-        (void)hipMemcpy(&v, st.r + (int64_t)c * st.stride + slot, sizeof(R), hipMemcpyDeviceToHost);
-        std::fprintf(stderr, " %.17g", (double)v);
-    }
+    R rec[PATH_REC];
+    (void)hipMemcpy(rec, st.r + slot * PATH_REC, sizeof rec, hipMemcpyDeviceToHost);
+    for (int c = 0; c < PATH_REC; c++)
+        if (c != S_HIT && c != S_CTR && c != S_FLAGS) std::fprintf(stderr, " %.17g", (double)rec[c]);
     std::fprintf(stderr, " I:");
-    for (int c = 0; c < S_NUM_I; c++) {
-        int32_t v = 0;
-        (void)hipMemcpy(&v, st.i + (int64_t)c * st.stride + slot, sizeof(int32_t), hipMemcpyDeviceToHost);
-        std::fprintf(stderr, " %d", v);
-    }
+    for (int c : {(int)S_HIT, (int)S_CTR, (int)S_FLAGS}) std::fprintf(stderr, " %d", *reinterpret_cast<int32_t *>(&rec[c]));
     std::fprintf(stderr, "\n");
 }
 
@@ -341,7 +334,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     if (npix == 0) return TAKE_OK;
     if (npix >= ((int64_t)1 << 30)) return fail(TAKE_E_INVALID, "image too large");
 
-    const int64_t target = (int64_t)8 << 20;  // paths in flight per batch
+    const int64_t target = (int64_t)32 << 20;  // paths in flight per batch (128 B of state each in f32)
     int spb = o.samples_per_batch > 0 ? o.samples_per_batch : (int)std::max<int64_t>(1, target / npix);
     spb = std::min(spb, o.spp);
     while ((int64_t)spb * npix >= ((int64_t)1 << 31) - (1 << 26)) spb--;
@@ -349,7 +342,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     int rc = ensure_workspace(sc, slots, npix);
     if (rc) return rc;
 
-    PathState<R> st{sc.state_r.p, sc.state_i.p, sc.capacity};
+    PathState<R> st{sc.state_r.p, sc.capacity};
     RenderParams<R> rp{};
     rp.width = W, rp.height = H, rp.n_local_rows = n_rows, rp.npix = (int32_t)npix;
     rp.strip_first = first, rp.strip_stride = stride;

@@ -250,7 +250,9 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
     }
 
     // acceleration structure
-    Bvh2Builder builder(bp, max_leaf > 0 ? max_leaf : MAX_LEAF, threads);
+    // default leaf size 2: on triangle soups the tighter leaf boxes save more primitive tests than the extra
+    // interior nodes cost (1M soup: 48.5 node + 10.8 primitive tests per ray vs 42.6 + 42.6 with 4 per leaf)
+    Bvh2Builder builder(bp, max_leaf > 0 ? max_leaf : 2, threads);
     const int root = builder.build();
     std::vector<int32_t> order;
     hs.root_child = collapse_to_wide<R>(builder.nodes(), root, hs.nodes, order, hs.stats);

@@ -8,8 +8,8 @@
 //    leaf is one contiguous run; 48 B in f32.
 //  * Everything the shading stage needs (vertex normals, uvs, materials, lights, texels) is indexed by the
 //    shape id a hit returns; it is touched once per bounce, not per node.
-//  * Path state is SoA with component stride = slots in flight: lane i of a wave touches element i of
-//    each component array -> coalesced.
+//  * Path state is one 128-byte record per path (f32): queues are compacted every bounce, so live slots are
+//    scattered and a lane should consume whole cache lines (see PathState below).
 #pragma once
 
 #include "tk_common.h"
@@ -110,29 +110,33 @@ template <class R> struct DeviceScene {
     CameraRec<R> cam;
 };
 
-// ---- path state: component c of slot s lives at base[c * stride + s]
+// ---- path state: one PATH_REC-word record per path slot (128 B in f32, 256 B in f64).
+// Queues are compacted every round, so after a few bounces the live slots are scattered: with one array per
+// component every 4-byte access of a wave touched its own cache line (measured: the shade kernel moved 5x its
+// algorithmic bytes).  With a record per path a lane consumes whole lines.  The first 64 B hold what the
+// closest-hit kernel touches (ray, hit record), the rest what only the shade / shadow kernels need.
 enum StateR {
-    S_OX, S_OY, S_OZ,   // ray origin = position of the current vertex
-    S_DX, S_DY, S_DZ,   // ray direction (extend ray)
-    S_TX, S_TY, S_TZ,   // throughput
-    S_LX, S_LY, S_LZ,   // radiance of this sample so far
-    S_FX, S_FY, S_FZ,   // FG of the pending BSDF sample
-    S_PDF,              // its pdf
-    S_HT, S_HU, S_HV,   // closest-hit record of the extend ray
-    S_SX, S_SY, S_SZ,   // shadow-ray direction
-    S_ST,               // shadow-ray tmax
-    S_CX, S_CY, S_CZ,   // throughput * C1: added to radiance if the shadow ray is unoccluded
-    S_NUM_R
+    S_OX = 0, S_OY, S_OZ,      // ray origin = position of the current vertex
+    S_DX, S_DY, S_DZ,          // ray direction (extend ray)
+    S_HT, S_HU, S_HV,          // closest-hit record of the extend ray
+    S_PDF = 12,                // pdf of the pending BSDF sample
+    S_TX, S_TY, S_TZ,          // throughput
+    S_LX, S_LY, S_LZ,          // radiance of this sample so far
+    S_ST,                      // shadow-ray tmax
+    S_FX, S_FY, S_FZ,          // FG of the pending BSDF sample
+    S_SX, S_SY, S_SZ,          // shadow-ray direction
+    S_CX, S_CY, S_CZ,          // throughput * C1: added to radiance if the shadow ray is unoccluded
+    S_NUM_R = 29
 };
-enum StateI { S_HIT, S_CTR, S_FLAGS, S_NUM_I };
+enum StateI { S_HIT = 9, S_CTR = 10, S_FLAGS = 11, S_NUM_I = 3 };  // integer words of the same record
+constexpr int PATH_REC = 32;
 constexpr int32_t FLAG_SPECULAR = 1;
 
 template <class R> struct PathState {
-    R *r;        // S_NUM_R * stride
-    int32_t *i;  // S_NUM_I * stride
-    int64_t stride;
-    TK_HD R &R_(int c, int64_t s) const { return r[(int64_t)c * stride + s]; }
-    TK_HD int32_t &I_(int c, int64_t s) const { return i[(int64_t)c * stride + s]; }
+    R *r;            // PATH_REC * slots
+    int64_t stride;  // slots allocated (not used for addressing)
+    TK_HD R &R_(int c, int64_t s) const { return r[s * PATH_REC + c]; }
+    TK_HD int32_t &I_(int c, int64_t s) const { return *reinterpret_cast<int32_t *>(&r[s * PATH_REC + c]); }
 };
 
 // queue bookkeeping words (one small device array)

@@ -21,6 +21,13 @@
 
 namespace tk {
 
+// tuning knobs (overridable with -D for experiments)
+#ifndef TQ_MIN_WAVES
+#define TQ_MIN_WAVES 1
+#endif
+#ifndef TQ_PAIR_LEVELS
+#define TQ_PAIR_LEVELS 24
+#endif
 constexpr int TQ_BLOCK = 256;                 // 4 waves = 64 quads
 constexpr int TQ_QUADS = TQ_BLOCK / 4;
 constexpr int TQ_LEVELS = 32;                 // per-quad stack levels in LDS (8 B each: 17 KB per block)
@@ -135,7 +142,7 @@ template <int G> struct GroupGeom {
     static constexpr int CPL = 4 / G;                    // child slots per lane
     static constexpr int GROUPS = TQ_BLOCK / G;          // rays in flight per block
     static constexpr int PER_WAVE = 64 / G;
-    static constexpr int LEVELS = G == 4 ? 32 : (G == 2 ? 24 : 16);  // stack levels in LDS
+    static constexpr int LEVELS = G == 4 ? 32 : (G == 2 ? TQ_PAIR_LEVELS : 16);  // stack levels in LDS
     static constexpr int STRIDE = GROUPS + 4;            // entries per level (+4: 32 B skew between levels)
     static constexpr int SPILL = 100 - LEVELS;           // deeper levels in global memory; builder caps depth at 96
 };
@@ -151,7 +158,7 @@ template <int G> __device__ __forceinline__ int group_max_i(int v) {
 }
 
 template <class R, int G, bool ANY_HIT, bool COUNT, class Io>
-__global__ void __launch_bounds__(TQ_BLOCK)
+__global__ void __launch_bounds__(TQ_BLOCK, TQ_MIN_WAVES)
 k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_t n_direct, int32_t *head,
               unsigned long long *counters, int counter_word, QuadSpill spill) {
     using GG = GroupGeom<G>;

@@ -37,9 +37,10 @@ std::string g_err;
 
 template <class R> void dump_slot(const PathState<R> &st, int64_t slot, const char *tag, int k) {
     std::fprintf(stderr, "[slot %lld] k=%d %s R:", (long long)slot, k, tag);
-    for (int c = 0; c < S_NUM_R; c++) std::fprintf(stderr, " %.17g", (double)st.R_(c, slot));
+    for (int c = 0; c < PATH_REC; c++)
+        if (c != S_HIT && c != S_CTR && c != S_FLAGS) std::fprintf(stderr, " %.17g", (double)st.R_(c, slot));
     std::fprintf(stderr, " I:");
-    for (int c = 0; c < S_NUM_I; c++) std::fprintf(stderr, " %d", st.I_(c, slot));
+    for (int c : {(int)S_HIT, (int)S_CTR, (int)S_FLAGS}) std::fprintf(stderr, " %d", st.I_(c, slot));
     std::fprintf(stderr, "\n");
 }
 
@@ -61,9 +62,8 @@ template <class R> int render_t(const TakeSceneDesc &desc, const TakeRenderOpts 
     rp.ray_eps = o.ray_epsilon > 0 ? R(o.ray_epsilon) : (sizeof(R) == 8 ? R(1e-7) : R(1e-4));
     const int spb = o.samples_per_batch > 0 ? std::min(o.samples_per_batch, o.spp) : o.spp;
     const int64_t slots = (int64_t)spb * npix;
-    std::vector<R> sr((size_t)S_NUM_R * slots);
-    std::vector<int32_t> si((size_t)S_NUM_I * slots);
-    PathState<R> st{sr.data(), si.data(), slots};
+    std::vector<R> sr((size_t)PATH_REC * slots);
+    PathState<R> st{sr.data(), slots};
     std::vector<R> accum(3 * npix, R(0));
     std::vector<int32_t> q[2], shadow;
     uint64_t n_closest = 0, n_shadow = 0, n_nodes = 0, n_prims = 0, max_stack = 0;
