@@ -50,6 +50,35 @@ def parse_args():
     return ap.parse_args()
 
 
+def measured_traffic(args):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
+    (profiles/r01_traffic.json, written by tools/profile.sh -> tools/profile_summary.py; FETCH_SIZE and WRITE_SIZE
+    collected in separate passes).  None when the run is not the default configuration the profile was taken on."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    default = (args.tris, args.width, args.height, args.spp, args.max_depth, args.spb) == (1_000_000, 1920, 1080, 256, 50, 0)
+    if not (default and args.gpus == 1 and os.path.exists(path)):
+        return None
+    with open(path) as f:
+        return json.load(f).get("hbm_bytes_per_launch")
+
+
+def usable_cpus():
+    """host cores this process may actually use: affinity mask, cgroup v2 quota, and the GPU box's stated share
+    (16 CPUs per GPU) — os.cpu_count() reports the whole 256-thread host."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(args, sd_full):
     """Time the CPU path on a bounded sample of the same workload (same scene, fewer pixels / samples).
     Prefers the compiled reference itself (oracle/_ref/ref_harness, built in the authoring container);
@@ -57,7 +86,7 @@ def cpu_baseline(args, sd_full):
     from take_amd import scenes
 
     w, h, spp = (int(x) for x in args.cpu_sample.split("x"))
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     sd = scenes.soup_scene(args.tris, w, h, spp=spp, max_depth=args.max_depth)
     samples = w * h * spp
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
@@ -153,7 +182,7 @@ def main():
     if rank == 0:
         samples = args.width * args.height * spp_total * args.steps
         value = samples / elapsed / 1e6
-        # dominant kernel: tk::k_trace<float, false, false> (closest hit).  achieved = algorithmic bytes per launch
+        # dominant kernel: tk::k_trace_group<float, 2, false, false, PathIo<float>> (closest hit).  achieved = algorithmic bytes per launch
         # / average launch duration, both over the timed region (HIP events recorded on the render stream)
         n_launch = max(acc["launches_trace_closest"], 1)
         avg_ms = acc["ms_trace_closest"] / n_launch
@@ -175,8 +204,8 @@ def main():
                        "kernel_ms": {k: acc[k] for k in ("ms_trace_closest", "ms_trace_shadow", "ms_shade", "ms_other",
                                                          "ms_total")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "tk::k_trace<float,false,false> (closest hit)", "launches": n_launch,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args),
+                         "kernel": "tk::k_trace_group<float,2,false,false,PathIo<float>> (closest hit)", "launches": n_launch,
                          "avg_launch_ms": avg_ms, "bytes_per_ray": bytes_per_ray,
                          "rays_per_launch": acc["rays_closest"] / n_launch},
         }

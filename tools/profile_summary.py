@@ -44,3 +44,35 @@ for grp in ("fetch", "write", "tcc", "sq1", "sq2", "grbm"):
     for k in sorted(acc, key=lambda k: -sum(acc[k].values())):
         cs = "  ".join(f"{c}={v:.4g}" for c, v in sorted(acc[k].items()))
         print(f"{k:62s} n={len(ndisp[k]):5d}  {cs}")
+
+# ---- HBM-side traffic of the dominant kernel (closest-hit trace), per launch, for bench.py's roofline.traffic.
+# FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3 derived counters: TCC_EA0_RDREQ*64 B etc.).  MI355X_MICROARCH.md:
+# on gfx950 FETCH_SIZE under-reports a wide coalesced stream by exactly 2x; this kernel's accesses are 16-byte
+# pieces of scattered 128-byte lines, a pattern the guide calls uncalibrated — the raw counter value is reported and
+# the 2x-corrected value is given beside it as an upper bound.
+import json
+
+
+def counter_total(grp, counter, key):
+    files = find(f"{grp}/**/*counter_collection.csv")
+    if not files:
+        return None, 0
+    tot, disp = 0.0, set()
+    for r in csv.DictReader(open(files[0])):
+        if key in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            tot += float(r["Counter_Value"])
+            disp.add(r["Dispatch_Id"])
+    return tot, len(disp)
+
+
+key = "false, false, tk::PathIo<float>"  # k_trace_group<float, G, ANY_HIT=false, COUNT=false, PathIo<float>>
+fetch, nf = counter_total("fetch", "FETCH_SIZE", key)
+write, nw = counter_total("write", "WRITE_SIZE", key)
+if fetch is not None and nf:
+    t = {"kernel": "tk::k_trace_group<float,2,false,false,PathIo<float>> (closest hit)", "launches": nf,
+         "fetch_bytes_per_launch": fetch * 1024 / nf, "write_bytes_per_launch": (write or 0) * 1024 / max(nw, 1),
+         "fetch_bytes_per_launch_x2_corrected": 2 * fetch * 1024 / nf}
+    t["hbm_bytes_per_launch"] = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
+    with open(os.path.join(out, "traffic.json"), "w") as f:
+        json.dump(t, f, indent=1)
+    print("\n## traffic.json\n" + json.dumps(t, indent=1))
