@@ -80,6 +80,7 @@ template <class R> struct SceneT {
     HostScene<R> host;  // kept: cheap relative to HBM copies, used for stats
     DevBuf<Node4<R>> nodes;
     DevBuf<PrimRec<R>> prims;
+    DevBuf<PrimShade> prim_shade;
     DevBuf<ShapeInfo> shapes;
     DevBuf<MeshInfo> meshes;
     DevBuf<int32_t> face_idx;
@@ -101,11 +102,11 @@ template <class R> struct SceneT {
     int64_t spill_stride = 0;  // ray groups in the persistent trace grid
 
     size_t scene_bytes() const {
-        return nodes.bytes() + prims.bytes() + shapes.bytes() + meshes.bytes() + face_idx.bytes() + normals.bytes() +
+        return nodes.bytes() + prims.bytes() + prim_shade.bytes() + shapes.bytes() + meshes.bytes() + face_idx.bytes() + normals.bytes() +
                uvs.bytes() + texels.bytes() + materials.bytes() + images.bytes() + lights.bytes();
     }
     void release() {
-        nodes.release(), prims.release(), shapes.release(), meshes.release(), face_idx.release();
+        nodes.release(), prims.release(), prim_shade.release(), shapes.release(), meshes.release(), face_idx.release();
         normals.release(), uvs.release(), texels.release(), materials.release(), images.release(), lights.release();
         state_r.release(), queue[0].release(), queue[1].release(), shadow_queue.release();
         sorted_queue.release(), accum.release(), out.release(), qwords.release(), counters.release(), spill.release();
@@ -143,6 +144,7 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     const HostScene<R> &h = sc.host;
     HIP_TRY(sc.nodes.upload(h.nodes));
     HIP_TRY(sc.prims.upload(h.prims));
+    HIP_TRY(sc.prim_shade.upload(h.prim_shade));
     HIP_TRY(sc.shapes.upload(h.shapes));
     HIP_TRY(sc.meshes.upload(h.meshes));
     HIP_TRY(sc.face_idx.upload(h.face_idx));
@@ -156,6 +158,7 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     d = h.view();
     d.nodes = sc.nodes.p;
     d.prims = sc.prims.p;
+    d.prim_shade = sc.prim_shade.p;
     d.shapes = sc.shapes.p;
     d.meshes = sc.meshes.p;
     d.face_idx = sc.face_idx.p;
@@ -381,6 +384,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
         hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, stream, q, (int)Q_N_EXT0, (int32_t)n);
         tm.end();
         const int rounds = o.max_depth + 2;
+        int64_t n_bound = n;  // upper bound of the extend-queue length (queues only shrink)
         for (int k = 0; k < rounds; k++) {
             const int cur = k & 1, next = cur ^ 1;
             int32_t *n_cur = q + (cur ? Q_N_EXT1 : Q_N_EXT0), *n_next = q + (next ? Q_N_EXT1 : Q_N_EXT0);
@@ -402,8 +406,9 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
             }
             tm.begin(TK_SHADE);
             {
+                const int shade_grid = (int)((n_bound + BLOCK - 1) / BLOCK);
                 ShadeArgs<R> sa{sc.dev, rp, st, shade_in, n_cur, sort_materials ? tag_count : nullptr, sc.queue[next].p,
-                                n_next, sc.shadow_queue.p, q + Q_N_SHADOW, k, sc.counters.p, wide_grid, stream};
+                                n_next, sc.shadow_queue.p, q + Q_N_SHADOW, k, sc.counters.p, shade_grid, stream};
                 if (sort_materials) {
                     // one specialised launch per material tag present in the scene + the miss segment
                     for (int t = 0; t < TAKE_MAT_COUNT; t++)
@@ -422,12 +427,14 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
                 tm.end();
                 if (dump >= 0 && dump < slots) dump_slot(st, dump, "after trace_shadow", k, stream);
             }
-            // every 8 rounds look at the queue length: stop launching once every path of the batch has ended
-            if ((k & 7) == 7 && k + 1 < rounds) {
+            // every 4 rounds look at the queue length: it bounds the shade grids of the following rounds, and
+            // launching stops once every path of the batch has ended
+            if ((k & 3) == 3 && k + 1 < rounds) {
                 int32_t alive = 0;
                 HIP_TRY(hipMemcpyAsync(&alive, n_next, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
                 if (alive == 0) break;
+                n_bound = alive;
             }
         }
         tm.begin(TK_OTHER);

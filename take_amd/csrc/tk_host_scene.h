@@ -16,6 +16,7 @@ namespace tk {
 template <class R> struct HostScene {
     std::vector<Node4<R>> nodes;
     std::vector<PrimRec<R>> prims;
+    std::vector<PrimShade> prim_shade;
     int32_t root_child = CHILD_EMPTY;
     std::vector<ShapeInfo> shapes;
     std::vector<MeshInfo> meshes;
@@ -36,6 +37,7 @@ template <class R> struct HostScene {
         DeviceScene<R> d{};
         d.nodes = nodes.data();
         d.prims = prims.data();
+        d.prim_shade = prim_shade.data();
         d.root_child = root_child;
         d.n_nodes = (int32_t)nodes.size();
         d.shapes = shapes.data();
@@ -257,7 +259,20 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
     std::vector<int32_t> order;
     hs.root_child = collapse_to_wide<R>(builder.nodes(), root, hs.nodes, order, hs.stats);
     hs.prims.resize(order.size());
-    for (size_t k = 0; k < order.size(); k++) hs.prims[k] = recs[bp[order[k]].id];
+    hs.prim_shade.resize(order.size());
+    for (size_t k = 0; k < order.size(); k++) {
+        hs.prims[k] = recs[bp[order[k]].id];
+        const ShapeInfo &si = hs.shapes[hs.prims[k].shape_id];
+        PrimShade ps{si.material, si.area_light, -1, si.mesh};
+        if (si.mesh >= 0) {
+            const MeshInfo &mi = hs.meshes[si.mesh];
+            if (mi.nbase >= 0 || mi.uvbase >= 0) {
+                ps.nidx = mi.fbase + si.face;
+                hs.prims[k].meta |= META_HAS_ATTR;
+            }
+        }
+        hs.prim_shade[k] = ps;
+    }
     if (3 * hs.stats.depth + 1 > 96) return "BVH too deep for the traversal stack";
     return "";
 }

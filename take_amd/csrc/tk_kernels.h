@@ -64,17 +64,40 @@ k_shade(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, const int32_t *_
         n = tag_count[TAG];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[C_BOUNCES], (unsigned long long)n);
-    const int32_t n_round = (n + WAVE - 1) / WAVE * WAVE;
-    for (int32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += gridDim.x * BLOCK) {
-        uint32_t req = 0;
-        int32_t slot = 0;
-        if (i < n) {
-            slot = queue[begin + i];
-            req = shade_path<R, TAG>(sc, rp, st, (int64_t)slot, k);
-        }
-        wave_append((req & REQ_EXTEND) != 0, slot, n_next, next_queue);
-        wave_append((req & REQ_SHADOW) != 0, slot, n_shadow, shadow_queue);
+    // one path per thread, no grid-stride loop: the grid covers an upper bound of the queue length the host knows
+    // (queues only shrink), so nothing loop-invariant is kept live across iterations (fewer SGPR/VGPR spills)
+    const int32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (blockIdx.x * BLOCK >= n) return;  // whole block beyond the queue (uniform)
+    uint32_t req = 0;
+    int32_t slot = 0;
+    if (i < n) {
+        slot = queue[begin + i];
+        req = shade_path<R, TAG>(sc, rp, st, (int64_t)slot, k);
     }
+    // Block-aggregated append to the two output queues: ballot + mbcnt inside each wave, wave counts combined in
+    // LDS, ONE atomicAdd per block and queue.  (One atomic per wave on a single counter word was the limit of this
+    // kernel: ~86 atomics/us, the rate MI355X_MICROARCH.md gives for one contended word.)
+    __shared__ int32_t s_cnt[2][BLOCK / WAVE];
+    __shared__ int32_t s_base[2];
+    const bool want_e = (req & REQ_EXTEND) != 0, want_s = (req & REQ_SHADOW) != 0;
+    const uint64_t me = __ballot(want_e), ms = __ballot(want_s);
+    const int wave = threadIdx.x / WAVE;
+    if (lane_id() == 0) {
+        s_cnt[0][wave] = (int32_t)__popcll(me);
+        s_cnt[1][wave] = (int32_t)__popcll(ms);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        int32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / WAVE; w++) tot += s_cnt[threadIdx.x][w];
+        s_base[threadIdx.x] = tot ? atomicAdd(threadIdx.x == 0 ? n_next : n_shadow, tot) : 0;
+    }
+    __syncthreads();
+    int32_t off_e = s_base[0], off_s = s_base[1];
+    for (int w = 0; w < wave; w++) off_e += s_cnt[0][w], off_s += s_cnt[1][w];
+    if (want_e) next_queue[off_e + mask_rank(me)] = slot;
+    if (want_s) shadow_queue[off_s + mask_rank(ms)] = slot;
 }
 
 // ---- material sort of the extend queue (after trace_closest, before shade): counting sort on the tag of the

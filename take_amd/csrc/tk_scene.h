@@ -51,6 +51,17 @@ static_assert(sizeof(PrimRec<float>) == 48, "48-byte f32 primitive record");
 static_assert(sizeof(PrimRec<double>) == 96 || sizeof(PrimRec<double>) == 88 || sizeof(PrimRec<double>) == 80,
               "f64 primitive record");
 
+// Shading-side record of a primitive, in leaf order like PrimRec (same index): what the shade kernel needs right
+// after a hit, without the prim -> shape -> mesh chain of dependent loads.
+struct PrimShade {
+    int32_t material;
+    int32_t area_light;
+    int32_t nidx;   // first of the face's 3 entries in face_idx (units: faces), or -1 when the mesh has neither
+                    // vertex normals nor uvs (then nothing else is read)
+    int32_t mesh;   // mesh id (valid when nidx >= 0)
+};
+constexpr int32_t META_HAS_ATTR = 1 << 16;  // PrimRec::meta flag: vertex normals and/or uvs exist
+
 struct ShapeInfo {  // indexed by shape id
     int32_t mesh;   // >= 0 mesh id (triangle); < 0: a sphere (-(1 + sphere id))
     int32_t face;   // face id within the mesh
@@ -93,6 +104,7 @@ template <class R> struct CameraRec {
 template <class R> struct DeviceScene {
     const Node4<R> *nodes;
     const PrimRec<R> *prims;
+    const PrimShade *prim_shade;  // same order as prims
     int32_t root_child;  // child word of the root (a leaf word when the scene has <= MAX_LEAF shapes)
     int32_t n_nodes;
     const ShapeInfo *shapes;

@@ -27,11 +27,11 @@ template <class R> TK_HD Vec3<R> ld3(const R *p) { return {p[0], p[1], p[2]}; }
 template <class R>
 TK_HD void make_isect(const DeviceScene<R> &sc, Vec3<R> ro, Vec3<R> rd, int32_t prim, R t, R u, R v, Isect<R> &out) {
     const PrimRec<R> &p = sc.prims[prim];
-    const ShapeInfo si = sc.shapes[p.shape_id];
-    out.material = si.material;
-    out.area_light = si.area_light;
+    const PrimShade ps = sc.prim_shade[prim];  // independent of the PrimRec load: both are indexed by `prim`
+    out.material = ps.material;
+    out.area_light = ps.area_light;
     out.pos = ro + rd * t;
-    if (si.mesh < 0) {
+    if ((p.meta & 0xff) == PRIM_SPHERE) {
         Vec3<R> n = normalize(out.pos - Vec3<R>{p.a[0], p.a[1], p.a[2]});
         n = dot(rd, n) < R(0) ? n : -n;
         out.gn = n;
@@ -45,19 +45,18 @@ TK_HD void make_isect(const DeviceScene<R> &sc, Vec3<R> ro, Vec3<R> rd, int32_t 
     Vec3<R> gn = normalize(cross(e1, e2));
     gn = dot(rd, gn) < R(0) ? gn : -gn;
     out.gn = gn;
-    const MeshInfo mi = sc.meshes[si.mesh];
-    const int32_t *idx = sc.face_idx + 3 * (int64_t)(mi.fbase + si.face);
+    out.uv = {u, v};
+    out.sn = gn;
+    if (ps.nidx < 0) return;  // mesh without vertex normals and uvs (src/shape.cpp:90,101)
+    const MeshInfo mi = sc.meshes[ps.mesh];
+    const int32_t *idx = sc.face_idx + 3 * (int64_t)ps.nidx;
     const int32_t i0 = idx[0], i1 = idx[1], i2 = idx[2];
-    if (mi.uvbase < 0) {
-        out.uv = {u, v};
-    } else {
+    if (mi.uvbase >= 0) {
         const R *uv = sc.uvs + 2 * (int64_t)mi.uvbase;
         Vec2<R> uv0{uv[2 * i0], uv[2 * i0 + 1]}, uv1{uv[2 * i1], uv[2 * i1 + 1]}, uv2{uv[2 * i2], uv[2 * i2 + 1]};
         out.uv = (R(1) - u - v) * uv0 + u * uv1 + v * uv2;
     }
-    if (mi.nbase < 0) {
-        out.sn = gn;
-    } else {
+    if (mi.nbase >= 0) {
         const R *nn = sc.normals + 3 * (int64_t)mi.nbase;
         Vec3<R> n0 = ld3(nn + 3 * i0), n1 = ld3(nn + 3 * i1), n2 = ld3(nn + 3 * i2);
         out.sn = normalize((R(1) - u - v) * n0 + u * n1 + v * n2);

@@ -28,12 +28,21 @@ namespace tk {
 #ifndef TQ_PAIR_LEVELS
 #define TQ_PAIR_LEVELS 24
 #endif
+#ifndef TQ_SWITCH_LANES
+#define TQ_SWITCH_LANES 32  // leave the node phase when fewer lanes than this (of 64) are at interior nodes
+#endif
+#ifndef TQ_REFILL_DIV
+#define TQ_REFILL_DIV 4     // refill when at least 1/TQ_REFILL_DIV of the wave's ray slots are idle
+#endif
+#ifndef TQ_NODE_ITERS_DEF
+#define TQ_NODE_ITERS_DEF 6
+#endif
 constexpr int TQ_BLOCK = 256;                 // 4 waves = 64 quads
 constexpr int TQ_QUADS = TQ_BLOCK / 4;
 constexpr int TQ_LEVELS = 32;                 // per-quad stack levels in LDS (8 B each: 17 KB per block)
 constexpr int TQ_STRIDE = TQ_QUADS + 4;       // level stride in entries: 544 B = 32 (mod 128) -> conflict-free quads
 constexpr int TQ_SPILL = 68;                  // deeper levels in global memory (per quad); builder caps depth at 96
-constexpr int TQ_NODE_ITERS = 12;             // at most this many node steps before the next leaf phase / refill check
+constexpr int TQ_NODE_ITERS = TQ_NODE_ITERS_DEF;             // at most this many node steps before the next leaf phase / refill check
 constexpr int TQ_NODE_MIN_QUADS = 6;          // leave the node phase when fewer quads than this are at interior nodes
 constexpr int TQ_REFILL_MIN = 4;              // refill when at least this many of the 16 quads are idle
 constexpr uint32_t TQ_KEY_INVALID = 0xFFFFFFFFu;
@@ -224,7 +233,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
         {
             const uint64_t idle0 = __ballot(!active);
             const int n_idle = (int)(__popcll(idle0) >> GG::LOG2);
-            if (n_idle * 4 >= GG::PER_WAVE) {  // at least a quarter of the wave's ray slots are idle
+            if (n_idle * TQ_REFILL_DIV >= GG::PER_WAVE) {  // enough of the wave's ray slots are idle
 #pragma unroll 1
                 for (int pass = 0; pass < 2; ++pass) {
                     const uint64_t idle = __ballot(!active);
@@ -274,7 +283,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
             const int n_node = (int)__popcll(__ballot(at_node));
             if (n_node == 0) break;
             // few groups left at interior nodes and some waiting at a leaf: switch to the leaf phase
-            if (n_node * 8 < 3 * 64 && __ballot(active && cur < 0) != 0) break;
+            if (n_node < TQ_SWITCH_LANES && __ballot(active && cur < 0) != 0) break;
             if (COUNT && lane == 0) cnt_wnode++;
             if (at_node) {
                 // CPL child slots per lane: 32-bit byte offset from the (scalar) node base
