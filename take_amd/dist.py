@@ -31,6 +31,8 @@ def gather_strips(local, height, rank, world, group=None, dst=0):
     None elsewhere.  One collective: a gather of equal-sized (padded) strip buffers."""
     if world == 1:
         return local
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        local = local.cpu()  # rehearsal on CPU process groups: gloo has no device gather
     width = local.shape[1]
     m = max_rows(height, world)
     padded = torch.zeros((m, width, 3), dtype=local.dtype, device=local.device)
