@@ -164,7 +164,7 @@ enum QueueWord {
 // instrumentation counters (device, 64-bit)
 enum CounterWord {
     C_NODE_VISITS, C_PRIM_TESTS, C_RAYS_CLOSEST, C_RAYS_SHADOW, C_BOUNCES, C_LEAF_VISITS, C_WAVE_NODE_STEPS,
-    C_WAVE_LEAF_STEPS, C_NUM_WORDS = 8
+    C_WAVE_LEAF_STEPS, C_WAIT_SLOTS, C_IDLE_SLOTS, C_NUM_WORDS = 12
 };
 
 }  // namespace tk

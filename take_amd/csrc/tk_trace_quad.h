@@ -45,9 +45,14 @@ constexpr int TQ_SPILL = 68;                  // deeper levels in global memory 
 constexpr int TQ_NODE_ITERS = TQ_NODE_ITERS_DEF;             // at most this many node steps before the next leaf phase / refill check
 constexpr int TQ_NODE_MIN_QUADS = 6;          // leave the node phase when fewer quads than this are at interior nodes
 constexpr int TQ_REFILL_MIN = 4;              // refill when at least this many of the 16 quads are idle
-constexpr uint32_t TQ_KEY_INVALID = 0xFFFFFFFFu;
+constexpr uint32_t TQ_KEY_INVALID = 0x7FFFFFFFu;  // above every finite non-negative float's bit pattern, below 2^31
 
 typedef unsigned long long tq_entry;          // low word: child word, high word: order key (float bits | lane)
+
+// wave-wide vote straight from the compare (HIP's __ballot goes through an integer 0/1 first)
+__device__ __forceinline__ uint64_t tq_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// 1 if a < b for keys below 2^31 (no carry/SGPR traffic: one subtract, one shift)
+__device__ __forceinline__ int tq_less(uint32_t a, uint32_t b) { return (int)((a - b) >> 31); }
 
 // ---- quad cross-lane helpers (DPP quad_perm: no LDS traffic)
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v) {
@@ -173,9 +178,11 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
     using GG = GroupGeom<G>;
     constexpr int CPL = GG::CPL;
     __shared__ tq_entry s_stack[GG::LEVELS * GG::STRIDE];
+    typedef __attribute__((address_space(3))) tq_entry lds_entry;
     const int lane = threadIdx.x & 63;
     const int gl = lane & (G - 1);            // lane within the group
     const int grp = threadIdx.x >> GG::LOG2;  // group within the block
+    lds_entry *const stk = (lds_entry *)&s_stack[grp];  // this group's column; level l at stk[l * STRIDE]
     tq_entry *const spl = spill.base + ((int64_t)blockIdx.x * GG::GROUPS + grp);
     const int32_t n = n_ptr ? *n_ptr : n_direct;
     if (blockIdx.x == 0 && threadIdx.x == 0 && counter_word >= 0)
@@ -196,7 +203,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
     // per-lane best candidate (differs between the lanes of a group)
     R my_t = Const<R>::inf(), my_u = R(0), my_v = R(0);
     int32_t my_prim = -1, my_shape = -1;
-    uint32_t cnt_nodes = 0, cnt_prims = 0, cnt_leaves = 0, cnt_wnode = 0, cnt_wleaf = 0;
+    uint32_t cnt_nodes = 0, cnt_prims = 0, cnt_leaves = 0, cnt_wnode = 0, cnt_wleaf = 0, cnt_wait = 0, cnt_idle = 0;
 
     // Next subtree that can still hold a closer hit (entries whose entry distance is beyond the closest hit are
     // dropped).  Returns true when the stack is empty: the ray is finished.
@@ -204,7 +211,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
         for (;;) {
             if (sp == 0) return true;
             --sp;
-            const tq_entry e = (sp < GG::LEVELS) ? s_stack[sp * GG::STRIDE + grp]
+            const tq_entry e = (sp < GG::LEVELS) ? stk[(uint32_t)sp * (uint32_t)GG::STRIDE]
                                                  : tq_spill_load(spl + (int64_t)(sp - GG::LEVELS) * spill.stride);
             cur = (int32_t)(uint32_t)e;
             const float key = __uint_as_float((uint32_t)(e >> 32) & ~3u);
@@ -231,12 +238,12 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
     for (;;) {
         // ------------------------------------------------------------------ refill idle groups from the pool
         {
-            const uint64_t idle0 = __ballot(!active);
+            const uint64_t idle0 = tq_ballot(!active);
             const int n_idle = (int)(__popcll(idle0) >> GG::LOG2);
             if (n_idle * TQ_REFILL_DIV >= GG::PER_WAVE) {  // enough of the wave's ray slots are idle
 #pragma unroll 1
                 for (int pass = 0; pass < 2; ++pass) {
-                    const uint64_t idle = __ballot(!active);
+                    const uint64_t idle = tq_ballot(!active);
                     if (idle == 0) break;
                     int32_t avail = pool_end - pool_next;
                     if (avail == 0) {
@@ -269,7 +276,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                 }
             }
         }
-        if (__ballot(active) == 0) {
+        if (tq_ballot(active) == 0) {
             if (exhausted) break;
             continue;
         }
@@ -280,11 +287,14 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
 #pragma unroll 1
         for (int it = 0; it < TQ_NODE_ITERS; ++it) {
             const bool at_node = active && cur >= 0;
-            const int n_node = (int)__popcll(__ballot(at_node));
+            const int n_node = (int)__popcll(tq_ballot(at_node));
             if (n_node == 0) break;
             // few groups left at interior nodes and some waiting at a leaf: switch to the leaf phase
-            if (n_node < TQ_SWITCH_LANES && __ballot(active && cur < 0) != 0) break;
-            if (COUNT && lane == 0) cnt_wnode++;
+            if (n_node < TQ_SWITCH_LANES && tq_ballot(active && cur < 0) != 0) break;
+            if (COUNT) {
+                const int nw = (int)__popcll(tq_ballot(active && cur < 0)), ni = (int)__popcll(tq_ballot(!active));
+                if (lane == 0) cnt_wnode++, cnt_wait += (uint32_t)(nw >> GG::LOG2), cnt_idle += (uint32_t)(ni >> GG::LOG2);
+            }
             if (at_node) {
                 // CPL child slots per lane: 32-bit byte offset from the (scalar) node base
                 if (COUNT && gl == 0) cnt_nodes++;
@@ -310,22 +320,23 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                 if (G == 4) {
                     const uint32_t k0 = (uint32_t)dpp_i<QP_B0>((int)key[0]), k1 = (uint32_t)dpp_i<QP_B1>((int)key[0]);
                     const uint32_t k2 = (uint32_t)dpp_i<QP_B2>((int)key[0]), k3 = (uint32_t)dpp_i<QP_B3>((int)key[0]);
-                    rank[0] = (int)(k0 < key[0]) + (int)(k1 < key[0]) + (int)(k2 < key[0]) + (int)(k3 < key[0]);
-                    nhit = (int)(k0 != TQ_KEY_INVALID) + (int)(k1 != TQ_KEY_INVALID) + (int)(k2 != TQ_KEY_INVALID) +
-                           (int)(k3 != TQ_KEY_INVALID);
+                    rank[0] = tq_less(k0, key[0]) + tq_less(k1, key[0]) + tq_less(k2, key[0]) + tq_less(k3, key[0]);
+                    nhit = tq_less(k0, TQ_KEY_INVALID) + tq_less(k1, TQ_KEY_INVALID) + tq_less(k2, TQ_KEY_INVALID) +
+                           tq_less(k3, TQ_KEY_INVALID);
                 } else if (G == 2) {
                     const uint32_t p0 = (uint32_t)dpp_i<QP_X1>((int)key[0]), p1 = (uint32_t)dpp_i<QP_X1>((int)key[CPL - 1]);
-                    rank[0] = (int)(key[CPL - 1] < key[0]) + (int)(p0 < key[0]) + (int)(p1 < key[0]);
-                    rank[CPL - 1] = (int)(key[0] < key[CPL - 1]) + (int)(p0 < key[CPL - 1]) + (int)(p1 < key[CPL - 1]);
-                    nhit = (int)(key[0] != TQ_KEY_INVALID) + (int)(key[CPL - 1] != TQ_KEY_INVALID) +
-                           (int)(p0 != TQ_KEY_INVALID) + (int)(p1 != TQ_KEY_INVALID);
+                    const int lt01 = tq_less(key[0], key[CPL - 1]);  // my two slots against each other (keys distinct)
+                    rank[0] = (1 - lt01) + tq_less(p0, key[0]) + tq_less(p1, key[0]);
+                    rank[CPL - 1] = lt01 + tq_less(p0, key[CPL - 1]) + tq_less(p1, key[CPL - 1]);
+                    nhit = tq_less(key[0], TQ_KEY_INVALID) + tq_less(key[CPL - 1], TQ_KEY_INVALID) +
+                           tq_less(p0, TQ_KEY_INVALID) + tq_less(p1, TQ_KEY_INVALID);
                 } else {
 #pragma unroll
                     for (int j = 0; j < CPL; j++) {
                         rank[j] = 0;
 #pragma unroll
-                        for (int i = 0; i < CPL; i++) rank[j] += (int)(key[i] < key[j]);
-                        nhit += (int)(key[j] != TQ_KEY_INVALID);
+                        for (int i = 0; i < CPL; i++) rank[j] += tq_less(key[i], key[j]);
+                        nhit += tq_less(key[j], TQ_KEY_INVALID);
                     }
                 }
                 // far-to-near: the nearest child ends on top of the stack and is popped right below
@@ -335,7 +346,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                         const int level = sp + nhit - 1 - rank[j];
                         const tq_entry e = ((tq_entry)key[j] << 32) | (tq_entry)(uint32_t)child[j];
                         if (level < GG::LEVELS)
-                            s_stack[level * GG::STRIDE + grp] = e;
+                            stk[(uint32_t)level * (uint32_t)GG::STRIDE] = e;
                         else
                             tq_spill_store(spl + (int64_t)(level - GG::LEVELS) * spill.stride, e);
                     }
@@ -347,7 +358,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
         // ------------------------------------------------------------------ leaf phase: primitives dealt to the lanes
         {
             const bool at_leaf = active && cur < 0 && cur != CHILD_EMPTY;
-            if (COUNT && lane == 0 && __ballot(at_leaf) != 0) cnt_wleaf++;
+            if (COUNT && lane == 0 && tq_ballot(at_leaf) != 0) cnt_wleaf++;
             if (at_leaf) {
                 const int first = leaf_first(cur), cnt = leaf_count(cur);
                 if (COUNT && gl == 0) cnt_prims += (uint32_t)cnt, cnt_leaves++;
@@ -388,6 +399,8 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
             atomicAdd(&counters[C_LEAF_VISITS], ll);
             atomicAdd(&counters[C_WAVE_NODE_STEPS], (unsigned long long)cnt_wnode);
             atomicAdd(&counters[C_WAVE_LEAF_STEPS], (unsigned long long)cnt_wleaf);
+            atomicAdd(&counters[C_WAIT_SLOTS], (unsigned long long)cnt_wait);
+            atomicAdd(&counters[C_IDLE_SLOTS], (unsigned long long)cnt_idle);
         }
     }
 }

@@ -6,12 +6,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from take_amd import capi, scenes
 
-PW = 64 // int(os.environ.get("TAKE_HIP_GROUP", "4"))  # ray slots per wave
+PW = 64 // int(os.environ.get("TAKE_HIP_GROUP", "2"))  # ray slots per wave
 tris = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
-sd = scenes.soup_scene(tris, 1920, 1080, spp=1)
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+sd = scenes.soup_scene(tris, 1920, 1080, spp=spp)
 sc = capi.Scene(sd)
 sc.set_instrumentation(timing=True, counting=True)
-sc.render(spp=1, max_depth=50, seed=0)
+sc.render(spp=spp, max_depth=50, seed=0)
 c = sc.counters()
 rays = c["rays_closest"] + c["rays_shadow"]
 print({k: c[k] for k in ("rays_closest", "rays_shadow", "node_visits", "leaf_visits", "prim_tests", "wave_node_steps",
