@@ -79,6 +79,7 @@ enum TimedKernel { TK_CLOSEST, TK_SHADOW, TK_SHADE, TK_OTHER, TK_NUM };
 template <class R> struct SceneT {
     HostScene<R> host;  // kept: cheap relative to HBM copies, used for stats
     DevBuf<Node4<R>> nodes;
+    DevBuf<QNode4> qnodes;
     DevBuf<PrimRec<R>> prims;
     DevBuf<PrimShade> prim_shade;
     DevBuf<ShapeInfo> shapes;
@@ -102,11 +103,11 @@ template <class R> struct SceneT {
     int64_t spill_stride = 0;  // ray groups in the persistent trace grid
 
     size_t scene_bytes() const {
-        return nodes.bytes() + prims.bytes() + prim_shade.bytes() + shapes.bytes() + meshes.bytes() + face_idx.bytes() + normals.bytes() +
+        return nodes.bytes() + qnodes.bytes() + prims.bytes() + prim_shade.bytes() + shapes.bytes() + meshes.bytes() + face_idx.bytes() + normals.bytes() +
                uvs.bytes() + texels.bytes() + materials.bytes() + images.bytes() + lights.bytes();
     }
     void release() {
-        nodes.release(), prims.release(), prim_shade.release(), shapes.release(), meshes.release(), face_idx.release();
+        nodes.release(), qnodes.release(), prims.release(), prim_shade.release(), shapes.release(), meshes.release(), face_idx.release();
         normals.release(), uvs.release(), texels.release(), materials.release(), images.release(), lights.release();
         state_r.release(), queue[0].release(), queue[1].release(), shadow_queue.release();
         sorted_queue.release(), accum.release(), out.release(), qwords.release(), counters.release(), spill.release();
@@ -142,7 +143,12 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     std::string err = prepare_scene<R>(desc, max_leaf, threads, sc.host);
     if (!err.empty()) return fail(TAKE_E_INVALID, err);
     const HostScene<R> &h = sc.host;
-    HIP_TRY(sc.nodes.upload(h.nodes));
+    sc.group = 2;  // pair traversal: measured fastest on MI355X (profiles/, DESIGN.md)
+    if (const char *g = std::getenv("TAKE_HIP_GROUP")) sc.group = std::atoi(g);  // tuning knob: lanes per ray (1, 2, 4)
+    if (sc.group != 1 && sc.group != 4) sc.group = 2;
+    const bool use_q = sc.group == 2 && !h.qnodes.empty();  // compressed nodes: f32 pair kernel
+    if (use_q) HIP_TRY(sc.qnodes.upload(h.qnodes));
+    else HIP_TRY(sc.nodes.upload(h.nodes));
     HIP_TRY(sc.prims.upload(h.prims));
     HIP_TRY(sc.prim_shade.upload(h.prim_shade));
     HIP_TRY(sc.shapes.upload(h.shapes));
@@ -157,6 +163,7 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     DeviceScene<R> &d = sc.dev;
     d = h.view();
     d.nodes = sc.nodes.p;
+    d.qnodes = use_q ? sc.qnodes.p : nullptr;
     d.prims = sc.prims.p;
     d.prim_shade = sc.prim_shade.p;
     d.shapes = sc.shapes.p;
@@ -174,15 +181,15 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     HIP_TRY(hipMemset(sc.counters.p, 0, sc.counters.bytes()));
     // persistent trace grid: resident blocks of the heaviest trace kernel x CUs
     int per_cu = 0;
-    sc.group = 2;  // pair traversal: measured fastest on MI355X (profiles/, DESIGN.md)
-    if (const char *g = std::getenv("TAKE_HIP_GROUP")) sc.group = std::atoi(g);  // tuning knob: lanes per ray (1, 2, 4)
-    if (sc.group != 1 && sc.group != 4) sc.group = 2;
     int groups_per_block = 0, spill_levels = 0;
     if (sc.group == 4) {
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 4, false, false, PathIo<R>>, TQ_BLOCK, 0));
         groups_per_block = GroupGeom<4>::GROUPS, spill_levels = GroupGeom<4>::SPILL;
     } else if (sc.group == 2) {
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>>, TQ_BLOCK, 0));
+        if constexpr (sizeof(R) == 4) {
+            if (use_q) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>, true>, TQ_BLOCK, 0));
+        }
+        if (!use_q) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>>, TQ_BLOCK, 0));
         groups_per_block = GroupGeom<2>::GROUPS, spill_levels = GroupGeom<2>::SPILL;
     } else {
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 1, false, false, PathIo<R>>, TQ_BLOCK, 0));
@@ -256,9 +263,10 @@ template <class R, class Io>
 void launch_trace(int group, bool any, bool count, dim3 grid, hipStream_t stream, const DeviceScene<R> &dev, const Io &io,
                   const int32_t *n_ptr, int32_t n_direct, int32_t *head, unsigned long long *counters, int counter_word,
                   QuadSpill spill) {
-#define TK_LAUNCH(G, A, C)                                                                                           \
-    hipLaunchKernelGGL((k_trace_group<R, G, A, C, Io>), grid, dim3(TQ_BLOCK), 0, stream, dev, io, n_ptr, n_direct, head, \
+#define TK_LAUNCH_Q(G, A, C, Q)                                                                                         \
+    hipLaunchKernelGGL((k_trace_group<R, G, A, C, Io, Q>), grid, dim3(TQ_BLOCK), 0, stream, dev, io, n_ptr, n_direct, head, \
                        counters, counter_word, spill)
+#define TK_LAUNCH(G, A, C) TK_LAUNCH_Q(G, A, C, false)
 #define TK_LAUNCH_G(G)                     \
     do {                                   \
         if (any && count) TK_LAUNCH(G, true, true);        \
@@ -266,10 +274,20 @@ void launch_trace(int group, bool any, bool count, dim3 grid, hipStream_t stream
         else if (count) TK_LAUNCH(G, false, true);         \
         else TK_LAUNCH(G, false, false);                   \
     } while (0)
+    if constexpr (sizeof(R) == 4) {
+        if (group == 2 && dev.qnodes) {  // compressed nodes
+            if (any && count) TK_LAUNCH_Q(2, true, true, true);
+            else if (any) TK_LAUNCH_Q(2, true, false, true);
+            else if (count) TK_LAUNCH_Q(2, false, true, true);
+            else TK_LAUNCH_Q(2, false, false, true);
+            return;
+        }
+    }
     if (group == 4) TK_LAUNCH_G(4);
     else if (group == 2) TK_LAUNCH_G(2);
     else TK_LAUNCH_G(1);
 #undef TK_LAUNCH_G
+#undef TK_LAUNCH_Q
 #undef TK_LAUNCH
 }
 
@@ -332,7 +350,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     const int n_rows = rows_of(H, first, stride, nullptr);
     const int64_t npix = (int64_t)n_rows * W;
     ts->counters = TakeCounters{};
-    ts->counters.node_bytes = sizeof(Node4<R>);
+    ts->counters.node_bytes = sc.dev.qnodes ? sizeof(QNode4) : sizeof(Node4<R>);
     ts->counters.prim_bytes = sizeof(PrimRec<R>);
     if (npix == 0) return TAKE_OK;
     if (npix >= ((int64_t)1 << 30)) return fail(TAKE_E_INVALID, "image too large");
@@ -501,7 +519,7 @@ int trace_impl(TakeScene *ts, const void *d_rays, int64_t n, void *d_hits, int32
     unsigned long long c[C_NUM_WORDS];
     HIP_TRY(hipMemcpy(c, sc.counters.p, sizeof c, hipMemcpyDeviceToHost));
     ts->counters = TakeCounters{};
-    ts->counters.node_bytes = sizeof(Node4<R>);
+    ts->counters.node_bytes = sc.dev.qnodes ? sizeof(QNode4) : sizeof(Node4<R>);
     ts->counters.prim_bytes = sizeof(PrimRec<R>);
     (any ? ts->counters.rays_shadow : ts->counters.rays_closest) = (uint64_t)n;
     ts->counters.node_visits = c[C_NODE_VISITS];

@@ -270,4 +270,66 @@ int32_t collapse_to_wide(const std::vector<Bvh2Node> &n2, int root, std::vector<
     return 0;  // root node index
 }
 
+// Compressed copy of the f32 nodes (QNode4, tk_scene.h) on one 16-bit grid over the union of all child boxes.
+// Per axis: step = extent / 65535 rounded up to a float with slack, every child plane is moved outwards by
+// delta = 65535 * step * 2^-21 and then snapped outwards to the grid.  delta pays for the rounding of the grid-space
+// slab test (tk_traverse.h: qray_make); the checks below are on exact values (a float plus a 16-bit multiple of a
+// float is exact in double to ~1e-16 relative, nothing next to delta).
+// Returns the surface-area inflation of the decoded boxes (sum of decoded half-areas / sum of true half-areas):
+// the expected growth in node visits for random rays; the caller keeps the full-width nodes when it is large.
+inline double quantise_nodes(const std::vector<Node4<float>> &in, std::vector<QNode4> &out, float grid_lo[3],
+                             float grid_step[3]) {
+    out.assign(in.size(), QNode4{});
+    const double inf = std::numeric_limits<double>::infinity();
+    double lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf}, delta[3];
+    for (const Node4<float> &nd : in)
+        for (int i = 0; i < 4; i++)
+            if (nd.c[i].child != CHILD_EMPTY)
+                for (int a = 0; a < 3; a++) lo[a] = std::min(lo[a], (double)nd.c[i].bmin[a]), hi[a] = std::max(hi[a], (double)nd.c[i].bmax[a]);
+    auto float_down = [](double x) {
+        float f = (float)x;
+        if ((double)f > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+        return f;
+    };
+    for (int a = 0; a < 3; a++) {
+        if (!(lo[a] <= hi[a])) lo[a] = hi[a] = 0.0;
+        double ext = hi[a] - lo[a];
+        if (!(ext > 0)) ext = std::max(std::fabs(lo[a]), 1.0) * 1e-6;  // flat scene on this axis: any small grid will do
+        float step = (float)(ext * (1.0 + 1e-5) / 65535.0);
+        float p = 0;
+        for (;; step = std::nextafterf(step * 1.0001f, std::numeric_limits<float>::infinity())) {
+            delta[a] = 65535.0 * (double)step * 0x1p-21;
+            p = float_down(lo[a] - delta[a]);
+            if ((double)p + 65535.0 * (double)step >= hi[a] + delta[a]) break;
+        }
+        grid_lo[a] = p, grid_step[a] = step;
+    }
+    double area_true = 0, area_q = 0;
+    for (size_t n = 0; n < in.size(); n++) {
+        const Node4<float> &nd = in[n];
+        QNode4 q{};
+        for (int i = 0; i < 4; i++) {
+            q.c[i].child = nd.c[i].child;
+            if (nd.c[i].child == CHILD_EMPTY) continue;
+            double et[3], eq[3];
+            for (int a = 0; a < 3; a++) {
+                const double p = grid_lo[a], step = grid_step[a];
+                const double l = (double)nd.c[i].bmin[a] - delta[a], h = (double)nd.c[i].bmax[a] + delta[a];
+                long ql = (long)std::floor((l - p) / step);
+                while (p + ql * step > l) ql--;
+                long qh = (long)std::ceil((h - p) / step);
+                while (p + qh * step < h) qh++;
+                ql = std::max(ql, 0L), qh = std::min(qh, 65535L);  // no-ops by construction of grid_lo and grid_step
+                q.c[i].q[a] = (uint32_t)ql | ((uint32_t)qh << 16);
+                et[a] = (double)nd.c[i].bmax[a] - (double)nd.c[i].bmin[a];
+                eq[a] = (double)(qh - ql) * step;
+            }
+            area_true += et[0] * et[1] + et[1] * et[2] + et[2] * et[0];
+            area_q += eq[0] * eq[1] + eq[1] * eq[2] + eq[2] * eq[0];
+        }
+        out[n] = q;
+    }
+    return area_true > 0 ? area_q / area_true : 1.0;
+}
+
 }  // namespace tk

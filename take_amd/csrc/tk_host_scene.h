@@ -4,6 +4,7 @@
 // parse_scene and the tile loop (src/render.cpp:37-50) plus build_bvh (src/scene.cpp:4-23).
 #pragma once
 
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -15,6 +16,9 @@ namespace tk {
 
 template <class R> struct HostScene {
     std::vector<Node4<R>> nodes;
+    std::vector<QNode4> qnodes;  // f32: compressed copy of nodes (empty = not in use)
+    float grid_lo[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1};
+    double q_inflation = 1.0;    // surface-area inflation of the compressed boxes (1 = none)
     std::vector<PrimRec<R>> prims;
     std::vector<PrimShade> prim_shade;
     int32_t root_child = CHILD_EMPTY;
@@ -36,6 +40,8 @@ template <class R> struct HostScene {
     DeviceScene<R> view() const {
         DeviceScene<R> d{};
         d.nodes = nodes.data();
+        d.qnodes = qnodes.empty() ? nullptr : qnodes.data();
+        for (int a = 0; a < 3; a++) d.grid_lo[a] = grid_lo[a], d.grid_step[a] = grid_step[a];
         d.prims = prims.data();
         d.prim_shade = prim_shade.data();
         d.root_child = root_child;
@@ -258,6 +264,18 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
     const int root = builder.build();
     std::vector<int32_t> order;
     hs.root_child = collapse_to_wide<R>(builder.nodes(), root, hs.nodes, order, hs.stats);
+    hs.qnodes.clear();
+    if constexpr (sizeof(R) == 4) {
+        // f32 scenes traverse the 64-byte compressed nodes unless the 16-bit scene grid is too coarse for the
+        // geometry (boxes growing by more than 10 % in area: a scene mixing scales by >1e4), or on request
+        // (TAKE_HIP_NODES=wide / =q16: A/B runs)
+        const char *fmt = std::getenv("TAKE_HIP_NODES");
+        const std::string f = fmt ? fmt : "";
+        if (f != "wide" && !hs.nodes.empty()) {
+            hs.q_inflation = quantise_nodes(hs.nodes, hs.qnodes, hs.grid_lo, hs.grid_step);
+            if (hs.q_inflation > 1.10 && f != "q16") hs.qnodes.clear();
+        }
+    }
     hs.prims.resize(order.size());
     hs.prim_shade.resize(order.size());
     for (size_t k = 0; k < order.size(); k++) {

@@ -37,6 +37,24 @@ template <class R> struct alignas(16) Node4 {
 };
 static_assert(sizeof(NodeChild<float>) == 32 && sizeof(Node4<float>) == 128, "one L2 line per f32 node");
 
+// Compressed wide node of the f32 render path: 64 B, two per cache line.  The child boxes are stored on ONE 16-bit
+// grid that spans the whole scene: plane = grid_lo[a] + q * grid_step[a]  (q in 0..65535, DeviceScene::grid_*),
+// rounded outwards, so the decoded box contains the true one (tk_bvh.h: quantise_nodes).  A cell is 1.5e-5 of the
+// scene extent — far below a primitive's size unless the scene mixes scales by more than ~1e4, in which case the
+// builder keeps the full-width nodes (tk_host_scene.h).
+// Why: the traversal is bound by the vector L1, which pays one line look-up per ray and per load instruction, and
+// by VALU issue at the same time (profiles/r01_tcp_counters.txt, r01_ubench_gather.txt).  A slot is
+// 16 B: the pair kernel reads its two slots with 2 x dwordx4 per lane instead of 4, with no cross-lane exchange,
+// and because the grid is global the ray is moved into grid space once per ray, not once per node.
+struct QChild {
+    uint32_t q[3];  // axis a: lo | hi << 16
+    int32_t child;  // child word (node index / leaf word / CHILD_EMPTY)
+};
+struct alignas(64) QNode4 {
+    QChild c[4];
+};
+static_assert(sizeof(QNode4) == 64, "64-byte compressed node");
+
 constexpr int32_t PRIM_TRIANGLE = 0;
 constexpr int32_t PRIM_SPHERE = 1;
 // triangle: a = v0.xyz, e1.xyz, e2.xyz (e = v_k - v0 in R arithmetic, as the reference computes per test,
@@ -103,6 +121,8 @@ template <class R> struct CameraRec {
 // All device pointers of one scene.  Passed to kernels by value.
 template <class R> struct DeviceScene {
     const Node4<R> *nodes;
+    const QNode4 *qnodes;  // f32 only: compressed copy of nodes (same indices); nullptr = traverse the full-width nodes
+    float grid_lo[3], grid_step[3];  // the quantisation grid of qnodes
     const PrimRec<R> *prims;
     const PrimShade *prim_shade;  // same order as prims
     int32_t root_child;  // child word of the root (a leaf word when the scene has <= MAX_LEAF shapes)

@@ -67,6 +67,7 @@ template <int CTRL> __device__ __forceinline__ double dpp_f(double v) {
 }
 constexpr int QP_B0 = 0x00, QP_B1 = 0x55, QP_B2 = 0xAA, QP_B3 = 0xFF;  // broadcast lane i of the quad
 constexpr int QP_X1 = 0xB1;                                            // [1,0,3,2]
+constexpr int QP_EVEN = 0xA0, QP_ODD = 0xF5;                           // [0,0,2,2] / [1,1,3,3]: one lane of each pair
 constexpr int QP_X2 = 0x4E;                                            // [2,3,0,1]
 template <class R> __device__ __forceinline__ R quad_min(R v) {
     v = tk_fmin(v, dpp_f<QP_X1>(v));
@@ -171,7 +172,8 @@ template <int G> __device__ __forceinline__ int group_max_i(int v) {
     return v;
 }
 
-template <class R, int G, bool ANY_HIT, bool COUNT, class Io>
+// QN: traverse the 64-byte compressed nodes (sc.qnodes; f32 pairs only) instead of the 128-byte ones.
+template <class R, int G, bool ANY_HIT, bool COUNT, class Io, bool QN = false>
 __global__ void __launch_bounds__(TQ_BLOCK, TQ_MIN_WAVES)
 k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_t n_direct, int32_t *head,
               unsigned long long *counters, int counter_word, QuadSpill spill) {
@@ -187,38 +189,49 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
     const int32_t n = n_ptr ? *n_ptr : n_direct;
     if (blockIdx.x == 0 && threadIdx.x == 0 && counter_word >= 0)
         atomicAdd(&counters[counter_word], (unsigned long long)n);
-    const char *const node_base = (const char *)sc.nodes;
+    static_assert(!QN || (G == 2 && sizeof(R) == 4), "compressed nodes: f32 pair kernel only");
+    const char *const node_base = QN ? (const char *)sc.qnodes : (const char *)sc.nodes;
     const char *const prim_base = (const char *)sc.prims;
 
     // wave-local pool of queue indices [pool_next, pool_end), refilled 64 at a time
     int32_t pool_next = 0, pool_end = 0;
     bool exhausted = false;
     // per-group traversal state (identical in the G lanes unless noted)
-    bool active = false;
     RayT<R> ray{};
     R idx = R(0), idy = R(0), idz = R(0), tbest = R(0);
+    QRay qr{};  // QN: the ray in grid space (replaces idx/idy/idz, which are dead then)
     int64_t tag = 0;
-    int sp = 0;
-    int32_t cur = CHILD_EMPTY;
+    int sp = 0;                 // entries on this group's stack
+    int32_t cur = CHILD_EMPTY;  // >= 0: at an interior node; < 0: at a leaf; CHILD_EMPTY: the slot holds no ray
     // per-lane best candidate (differs between the lanes of a group)
     R my_t = Const<R>::inf(), my_u = R(0), my_v = R(0);
     int32_t my_prim = -1, my_shape = -1;
     uint32_t cnt_nodes = 0, cnt_prims = 0, cnt_leaves = 0, cnt_wnode = 0, cnt_wleaf = 0, cnt_wait = 0, cnt_idle = 0;
 
+    // The trace kernels are bound by VALU issue (profiles/): stack addressing uses 24-bit multiplies
+    // (full rate; the 32x32 and 64-bit forms the compiler picks for plain indexing are quarter rate).
+    typedef __attribute__((address_space(3))) char lds_char;
+    constexpr uint32_t LEVEL_BYTES = (uint32_t)GG::STRIDE * 8u;
+    auto lds_level = [&](int level) -> lds_entry * { return (lds_entry *)((lds_char *)stk + __umul24((uint32_t)level, LEVEL_BYTES)); };
+    auto push_entry = [&](int level, tq_entry e) {
+        if (level < GG::LEVELS)
+            *lds_level(level) = e;
+        else
+            tq_spill_store(spl + (int64_t)(level - GG::LEVELS) * spill.stride, e);
+    };
     // Next subtree that can still hold a closer hit (entries whose entry distance is beyond the closest hit are
     // dropped).  Returns true when the stack is empty: the ray is finished.
     auto advance = [&]() -> bool {
         for (;;) {
             if (sp == 0) return true;
             --sp;
-            const tq_entry e = (sp < GG::LEVELS) ? stk[(uint32_t)sp * (uint32_t)GG::STRIDE]
-                                                 : tq_spill_load(spl + (int64_t)(sp - GG::LEVELS) * spill.stride);
+            const tq_entry e = (sp < GG::LEVELS) ? *lds_level(sp) : tq_spill_load(spl + (int64_t)(sp - GG::LEVELS) * spill.stride);
             cur = (int32_t)(uint32_t)e;
             const float key = __uint_as_float((uint32_t)(e >> 32) & ~3u);
             if ((R)key <= tbest) return false;
         }
     };
-    // ONE lane of the group writes the result
+    // ONE lane of the group writes the result; the slot becomes idle
     auto finish = [&]() {
         if (ANY_HIT) {
             const bool occ = group_max_i<G>(my_prim) >= 0;
@@ -232,18 +245,18 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                 io.store_hit(tag, my_prim, my_shape, my_t, my_u, my_v);
             }
         }
-        active = false;
+        cur = CHILD_EMPTY;
     };
 
     for (;;) {
         // ------------------------------------------------------------------ refill idle groups from the pool
         {
-            const uint64_t idle0 = tq_ballot(!active);
-            const int n_idle = (int)(__popcll(idle0) >> GG::LOG2);
+            const uint64_t idle0 = tq_ballot(cur == CHILD_EMPTY);
+            const int n_idle = __builtin_popcountll(idle0) >> GG::LOG2;
             if (n_idle * TQ_REFILL_DIV >= GG::PER_WAVE) {  // enough of the wave's ray slots are idle
 #pragma unroll 1
                 for (int pass = 0; pass < 2; ++pass) {
-                    const uint64_t idle = tq_ballot(!active);
+                    const uint64_t idle = tq_ballot(cur == CHILD_EMPTY);
                     if (idle == 0) break;
                     int32_t avail = pool_end - pool_next;
                     if (avail == 0) {
@@ -259,24 +272,25 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                         pool_end = min(base + 64, n);
                         avail = pool_end - pool_next;
                     }
-                    const int my_rank = (int)(__popcll(idle & ((1ull << (lane & ~(G - 1))) - 1ull)) >> GG::LOG2);
-                    if (!active && my_rank < avail) {
+                    const int my_rank = __builtin_popcountll(idle & ((1ull << (lane & ~(G - 1))) - 1ull)) >> GG::LOG2;
+                    if (cur == CHILD_EMPTY && my_rank < avail) {
                         io.template load<ANY_HIT>(pool_next + my_rank, ray, tag);
                         idx = safe_inv(ray.d.x), idy = safe_inv(ray.d.y), idz = safe_inv(ray.d.z);
+                        if constexpr (QN) qr = qray_make(sc.grid_lo, sc.grid_step, ray.o, idx, idy, idz);
                         tbest = ray.tmax;
                         sp = 0;
-                        cur = sc.root_child;
                         my_t = Const<R>::inf();
                         my_prim = -1;
                         my_shape = -1;
                         my_u = my_v = R(0);
-                        active = true;
+                        cur = sc.root_child;
+                        if (sc.root_child == CHILD_EMPTY) finish();  // empty scene: a miss, the slot stays idle
                     }
-                    pool_next += min(avail, (int32_t)(__popcll(idle) >> GG::LOG2));
+                    pool_next += min(avail, (int32_t)(__builtin_popcountll(idle) >> GG::LOG2));
                 }
             }
         }
-        if (tq_ballot(active) == 0) {
+        if (tq_ballot(cur != CHILD_EMPTY) == 0) {
             if (exhausted) break;
             continue;
         }
@@ -286,33 +300,49 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
         // separate phases keeps the leaf code out of the node steps.
 #pragma unroll 1
         for (int it = 0; it < TQ_NODE_ITERS; ++it) {
-            const bool at_node = active && cur >= 0;
-            const int n_node = (int)__popcll(tq_ballot(at_node));
-            if (n_node == 0) break;
+            const bool at_node = cur >= 0;
+            const uint64_t m_node = tq_ballot(at_node);
+            if (m_node == 0) break;
+            const uint64_t m_leaf = tq_ballot((uint32_t)cur > (uint32_t)CHILD_EMPTY);
             // few groups left at interior nodes and some waiting at a leaf: switch to the leaf phase
-            if (n_node < TQ_SWITCH_LANES && tq_ballot(active && cur < 0) != 0) break;
+            if (__builtin_popcountll(m_node) < TQ_SWITCH_LANES && m_leaf != 0) break;
             if (COUNT) {
-                const int nw = (int)__popcll(tq_ballot(active && cur < 0)), ni = (int)__popcll(tq_ballot(!active));
+                const int nw = __builtin_popcountll(m_leaf), ni = __builtin_popcountll(tq_ballot(cur == CHILD_EMPTY));
                 if (lane == 0) cnt_wnode++, cnt_wait += (uint32_t)(nw >> GG::LOG2), cnt_idle += (uint32_t)(ni >> GG::LOG2);
             }
             if (at_node) {
-                // CPL child slots per lane: 32-bit byte offset from the (scalar) node base
                 if (COUNT && gl == 0) cnt_nodes++;
-                const uint32_t off = (uint32_t)cur * (uint32_t)sizeof(Node4<R>) +
-                                     (uint32_t)(gl * CPL) * (uint32_t)sizeof(NodeChild<R>);
                 uint32_t key[CPL];
                 int32_t child[CPL];
+                if constexpr (QN) {
+                    // each lane loads its two 16-byte slots (planes on the scene grid + child word): one line
+                    // look-up per ray per instruction, no exchange between the lanes
+                    const uint32_t off = (uint32_t)cur * (uint32_t)sizeof(QNode4) + (uint32_t)(gl * CPL) * (uint32_t)sizeof(QChild);
 #pragma unroll
-                for (int j = 0; j < CPL; j++) {
-                    const NodeChild<R> c = *(const NodeChild<R> *)(node_base + off + j * (uint32_t)sizeof(NodeChild<R>));
-                    R tn;
-                    const bool ok = box_test(c, ray.o, idx, idy, idz, ray.tmin, tbest, tn);
-                    // order key: the (shrunk, hence conservative) entry distance as an integer — non-negative
-                    // floats order like their bit patterns — with the slot number in the two low bits, which makes
-                    // the four keys of a node distinct
-                    key[j] = ok ? ((__float_as_uint(stack_key(tn * Const<R>::BOX_SHRINK)) & ~3u) | (uint32_t)(gl * CPL + j))
-                                : TQ_KEY_INVALID;
-                    child[j] = c.child;
+                    for (int j = 0; j < CPL; j++) {
+                        const uint4 c = *(const uint4 *)(node_base + off + j * (uint32_t)sizeof(QChild));
+                        float tn;
+                        const bool ok = qbox_test(qr, c.x, c.y, c.z, (int32_t)c.w, ray.tmin, tbest, tn);
+                        key[j] = ok ? ((__float_as_uint(tn * Const<float>::BOX_SHRINK) & ~3u) | (uint32_t)(gl * CPL + j))
+                                    : TQ_KEY_INVALID;
+                        child[j] = (int32_t)c.w;
+                    }
+                } else {
+                    // CPL child slots per lane: 32-bit byte offset from the (scalar) node base
+                    const uint32_t off = (uint32_t)cur * (uint32_t)sizeof(Node4<R>) +
+                                         (uint32_t)(gl * CPL) * (uint32_t)sizeof(NodeChild<R>);
+#pragma unroll
+                    for (int j = 0; j < CPL; j++) {
+                        const NodeChild<R> c = *(const NodeChild<R> *)(node_base + off + j * (uint32_t)sizeof(NodeChild<R>));
+                        R tn;
+                        const bool ok = box_test(c, ray.o, idx, idy, idz, ray.tmin, tbest, tn);
+                        // order key: the (shrunk, hence conservative) entry distance as an integer — non-negative
+                        // floats order like their bit patterns — with the slot number in the two low bits, which
+                        // makes the four keys of a node distinct
+                        key[j] = ok ? ((__float_as_uint(stack_key(tn * Const<R>::BOX_SHRINK)) & ~3u) | (uint32_t)(gl * CPL + j))
+                                    : TQ_KEY_INVALID;
+                        child[j] = c.child;
+                    }
                 }
                 // rank of each of my slots among the four keys of the node (keys of the other lanes come by DPP;
                 // a key never compares less than itself, so broadcasting all four is fine)
@@ -328,8 +358,8 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                     const int lt01 = tq_less(key[0], key[CPL - 1]);  // my two slots against each other (keys distinct)
                     rank[0] = (1 - lt01) + tq_less(p0, key[0]) + tq_less(p1, key[0]);
                     rank[CPL - 1] = lt01 + tq_less(p0, key[CPL - 1]) + tq_less(p1, key[CPL - 1]);
-                    nhit = tq_less(key[0], TQ_KEY_INVALID) + tq_less(key[CPL - 1], TQ_KEY_INVALID) +
-                           tq_less(p0, TQ_KEY_INVALID) + tq_less(p1, TQ_KEY_INVALID);
+                    const int mine = tq_less(key[0], TQ_KEY_INVALID) + tq_less(key[CPL - 1], TQ_KEY_INVALID);
+                    nhit = mine + dpp_i<QP_X1>(mine);
                 } else {
 #pragma unroll
                     for (int j = 0; j < CPL; j++) {
@@ -339,25 +369,26 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                         nhit += tq_less(key[j], TQ_KEY_INVALID);
                     }
                 }
-                // far-to-near: the nearest child ends on top of the stack and is popped right below
+                if (nhit != 0) {
+                    // the nearest child is visited next and never touches the stack; the others are pushed
+                    // far-to-near, so the next nearest ends on top
+                    int32_t cand = CHILD_EMPTY;  // INT_MIN: below every child word
 #pragma unroll
-                for (int j = 0; j < CPL; j++) {
-                    if (key[j] != TQ_KEY_INVALID) {
-                        const int level = sp + nhit - 1 - rank[j];
-                        const tq_entry e = ((tq_entry)key[j] << 32) | (tq_entry)(uint32_t)child[j];
-                        if (level < GG::LEVELS)
-                            stk[(uint32_t)level * (uint32_t)GG::STRIDE] = e;
-                        else
-                            tq_spill_store(spl + (int64_t)(level - GG::LEVELS) * spill.stride, e);
+                    for (int j = 0; j < CPL; j++) {
+                        if (rank[j] == 0) cand = child[j];  // rank 0 with nhit != 0 is a hit
+                        if (key[j] != TQ_KEY_INVALID && rank[j] != 0)
+                            push_entry(sp + nhit - 1 - rank[j], ((tq_entry)key[j] << 32) | (tq_entry)(uint32_t)child[j]);
                     }
+                    sp += nhit - 1;
+                    cur = group_max_i<G>(cand);
+                } else if (advance()) {
+                    finish();
                 }
-                sp += nhit;
-                if (advance()) finish();
             }
         }
         // ------------------------------------------------------------------ leaf phase: primitives dealt to the lanes
         {
-            const bool at_leaf = active && cur < 0 && cur != CHILD_EMPTY;
+            const bool at_leaf = (uint32_t)cur > (uint32_t)CHILD_EMPTY;
             if (COUNT && lane == 0 && tq_ballot(at_leaf) != 0) cnt_wleaf++;
             if (at_leaf) {
                 const int first = leaf_first(cur), cnt = leaf_count(cur);
@@ -381,8 +412,6 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                 bool finished = ANY_HIT ? (group_max_i<G>(my_prim) >= 0) : false;
                 if (!finished) finished = advance();
                 if (finished) finish();
-            } else if (active && cur == CHILD_EMPTY) {
-                if (advance()) finish();  // empty scene: nothing to test
             }
         }
     }

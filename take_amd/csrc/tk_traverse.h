@@ -98,6 +98,47 @@ TK_HD bool box_test(const NodeChild<R> &c, Vec3<R> o, R idx, R idy, R idz, R tmi
     return (tn * Const<R>::BOX_SHRINK <= tf * Const<R>::BOX_GROW) && (c.child != CHILD_EMPTY);
 }
 
+// ---- compressed nodes (QNode4, f32 only).  The ray is moved into grid space once (QRay) instead of decoding planes:
+//   t(q) = (grid_lo + q step - o) / d = A + q B,   A = (grid_lo - o) * inv_d,   B = inv_d * step
+// Rounding: A carries two roundings, i.e. the plane looks displaced by <= |grid_lo - o| 2^-23.  When the origin is
+// within 4 grid extents of grid_lo that is <= extent 2^-21, which the builder adds to every child box before
+// snapping it outwards to the grid (tk_bvh.h: quantise_nodes; 0.03 cell); farther away it is a relative error of
+// the distance, which together with inv_d, B and the final fma rounding stays below 2 ulp, inside BOX_SHRINK /
+// BOX_GROW (3 ulp) like the full-width test.
+struct QRay {
+    float ax, ay, az, bx, by, bz;
+};
+TK_HD QRay qray_make(const float *grid_lo, const float *grid_step, Vec3<float> o, float idx, float idy, float idz) {
+    QRay f;
+    f.ax = (grid_lo[0] - o.x) * idx, f.ay = (grid_lo[1] - o.y) * idy, f.az = (grid_lo[2] - o.z) * idz;
+    f.bx = idx * grid_step[0], f.by = idy * grid_step[1], f.bz = idz * grid_step[2];
+    return f;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float tk_f2 __attribute__((ext_vector_type(2)));
+// both planes of one axis in one packed fma (v_pk_fma_f32): same value per element as the scalar form below
+__device__ __forceinline__ void qplanes(uint32_t w, float b, float a, float &t0, float &t1) {
+    const tk_f2 q = {(float)(w & 0xffffu), (float)(w >> 16)};
+    const tk_f2 t = __builtin_elementwise_fma(q, (tk_f2){b, b}, (tk_f2){a, a});
+    t0 = t.x, t1 = t.y;
+}
+#else
+inline void qplanes(uint32_t w, float b, float a, float &t0, float &t1) {
+    t0 = __builtin_fmaf((float)(w & 0xffffu), b, a);
+    t1 = __builtin_fmaf((float)(w >> 16), b, a);
+}
+#endif
+// conservative slab test of one compressed child slot
+TK_HD bool qbox_test(const QRay &f, uint32_t qx, uint32_t qy, uint32_t qz, int32_t child, float tmin, float tbest, float &tn) {
+    float t0x, t1x, t0y, t1y, t0z, t1z;
+    qplanes(qx, f.bx, f.ax, t0x, t1x);
+    qplanes(qy, f.by, f.ay, t0y, t1y);
+    qplanes(qz, f.bz, f.az, t0z, t1z);
+    tn = tk_fmax(tk_fmax(tk_fmin(t0x, t1x), tk_fmin(t0y, t1y)), tk_fmax(tk_fmin(t0z, t1z), tmin));
+    const float tf = tk_fmin(tk_fmin(tk_fmax(t0x, t1x), tk_fmax(t0y, t1y)), tk_fmin(tk_fmax(t0z, t1z), tbest));
+    return (tn * Const<float>::BOX_SHRINK <= tf * Const<float>::BOX_GROW) && (child != CHILD_EMPTY);
+}
+
 struct TravCount {
     uint32_t nodes = 0, prims = 0;
 };
@@ -112,20 +153,35 @@ TK_HD void traverse(const DeviceScene<R> &sc, const RayT<R> &ray, Stack &stack, 
     hit.u = hit.v = R(0);
     const R idx = safe_inv(ray.d.x), idy = safe_inv(ray.d.y), idz = safe_inv(ray.d.z);
     R tbest = ray.tmax;
+    QRay qr{};
+    if (sizeof(R) == 4 && sc.qnodes)
+        qr = qray_make(sc.grid_lo, sc.grid_step, Vec3<float>{(float)ray.o.x, (float)ray.o.y, (float)ray.o.z}, (float)idx,
+                       (float)idy, (float)idz);
     int sp = 0;
     int32_t cur = sc.root_child;
     for (;;) {
         if (cur >= 0) {
-            const Node4<R> &n = sc.nodes[cur];
             if (COUNT) tc.nodes++;
             R key[4];
             int32_t ch[4];
+            if (sizeof(R) == 4 && sc.qnodes) {  // compressed nodes (f32 scenes only: qnodes is null otherwise)
+                const QNode4 &n = sc.qnodes[cur];
+                for (int i = 0; i < 4; i++) {
+                    float tn;
+                    const bool ok = qbox_test(qr, n.c[i].q[0], n.c[i].q[1], n.c[i].q[2], n.c[i].child, (float)ray.tmin,
+                                              (float)tbest, tn);
+                    key[i] = ok ? (R)tn : Const<R>::inf();
+                    ch[i] = n.c[i].child;
+                }
+            } else {
+                const Node4<R> &n = sc.nodes[cur];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                R tn;
-                bool ok = box_test(n.c[i], ray.o, idx, idy, idz, ray.tmin, tbest, tn);
-                key[i] = ok ? tn : Const<R>::inf();
-                ch[i] = n.c[i].child;
+                for (int i = 0; i < 4; i++) {
+                    R tn;
+                    bool ok = box_test(n.c[i], ray.o, idx, idy, idz, ray.tmin, tbest, tn);
+                    key[i] = ok ? tn : Const<R>::inf();
+                    ch[i] = n.c[i].child;
+                }
             }
             // sorting network, ascending by entry distance
 #define TK_CSWAP(a, b)                        \
@@ -140,9 +196,9 @@ TK_HD void traverse(const DeviceScene<R> &sc, const RayT<R> &ray, Stack &stack, 
             TK_CSWAP(0, 1) TK_CSWAP(2, 3) TK_CSWAP(0, 2) TK_CSWAP(1, 3) TK_CSWAP(1, 2)
 #undef TK_CSWAP
             // far to near: deferred children go on the stack, the nearest is visited next
-            if (key[3] < Const<R>::inf()) stack.push(sp++, ch[3], stack_key(key[3]));
-            if (key[2] < Const<R>::inf()) stack.push(sp++, ch[2], stack_key(key[2]));
-            if (key[1] < Const<R>::inf()) stack.push(sp++, ch[1], stack_key(key[1]));
+            if (key[3] < Const<R>::inf()) stack.push(sp++, ch[3], stack_key(key[3] * Const<R>::BOX_SHRINK));
+            if (key[2] < Const<R>::inf()) stack.push(sp++, ch[2], stack_key(key[2] * Const<R>::BOX_SHRINK));
+            if (key[1] < Const<R>::inf()) stack.push(sp++, ch[1], stack_key(key[1] * Const<R>::BOX_SHRINK));
             if (key[0] < Const<R>::inf()) {
                 cur = ch[0];
                 continue;

@@ -192,7 +192,7 @@ def test_counters_consistent(soup100k):
     assert c["bounces"] == c["rays_closest"]  # every traced extend ray is shaded once
     assert c["node_visits"] > c["rays_closest"] and c["prim_tests"] > 0
     assert c["ms_trace_closest"] > 0 and c["ms_total"] >= c["ms_trace_closest"]
-    assert c["node_bytes"] == 128 and c["prim_bytes"] == 48
+    assert c["node_bytes"] in (64, 128) and c["prim_bytes"] == 48  # 64: compressed nodes (default), 128: TAKE_HIP_NODES=wide
 
 
 def test_white_furnace():
