@@ -227,6 +227,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
             --sp;
             const tq_entry e = (sp < GG::LEVELS) ? *lds_level(sp) : tq_spill_load(spl + (int64_t)(sp - GG::LEVELS) * spill.stride);
             cur = (int32_t)(uint32_t)e;
+            if (ANY_HIT) return false;  // the limit of a shadow ray never shrinks: nothing to cull
             const float key = __uint_as_float((uint32_t)(e >> 32) & ~3u);
             if ((R)key <= tbest) return false;
         }
@@ -344,45 +345,71 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                         child[j] = c.child;
                     }
                 }
-                // rank of each of my slots among the four keys of the node (keys of the other lanes come by DPP;
-                // a key never compares less than itself, so broadcasting all four is fine)
-                int rank[CPL], nhit = 0;
-                if (G == 4) {
-                    const uint32_t k0 = (uint32_t)dpp_i<QP_B0>((int)key[0]), k1 = (uint32_t)dpp_i<QP_B1>((int)key[0]);
-                    const uint32_t k2 = (uint32_t)dpp_i<QP_B2>((int)key[0]), k3 = (uint32_t)dpp_i<QP_B3>((int)key[0]);
-                    rank[0] = tq_less(k0, key[0]) + tq_less(k1, key[0]) + tq_less(k2, key[0]) + tq_less(k3, key[0]);
-                    nhit = tq_less(k0, TQ_KEY_INVALID) + tq_less(k1, TQ_KEY_INVALID) + tq_less(k2, TQ_KEY_INVALID) +
-                           tq_less(k3, TQ_KEY_INVALID);
-                } else if (G == 2) {
-                    const uint32_t p0 = (uint32_t)dpp_i<QP_X1>((int)key[0]), p1 = (uint32_t)dpp_i<QP_X1>((int)key[CPL - 1]);
-                    const int lt01 = tq_less(key[0], key[CPL - 1]);  // my two slots against each other (keys distinct)
-                    rank[0] = (1 - lt01) + tq_less(p0, key[0]) + tq_less(p1, key[0]);
-                    rank[CPL - 1] = lt01 + tq_less(p0, key[CPL - 1]) + tq_less(p1, key[CPL - 1]);
-                    const int mine = tq_less(key[0], TQ_KEY_INVALID) + tq_less(key[CPL - 1], TQ_KEY_INVALID);
-                    nhit = mine + dpp_i<QP_X1>(mine);
+                if constexpr (ANY_HIT && G == 2) {
+                    // shadow rays: any occluder ends the ray and the limit never shrinks, so the order of the
+                    // children does not matter and nothing is culled at pop time — no ranking, no keys.  The hit
+                    // slots are numbered lane 0 first; number 0 is visited next, the others are pushed.
+                    const int v0 = key[0] != TQ_KEY_INVALID, v1 = key[CPL - 1] != TQ_KEY_INVALID;
+                    const int mine = v0 + v1;
+                    const int theirs = dpp_i<QP_X1>(mine);
+                    const int nhit = mine + theirs;
+                    if (nhit != 0) {
+                        const int pos0 = gl ? theirs : 0, pos1 = pos0 + v0;
+                        int32_t cand = CHILD_EMPTY;  // INT_MIN: below every child word
+                        if (v0) {
+                            if (pos0 == 0) cand = child[0];
+                            else push_entry(sp + pos0 - 1, (tq_entry)(uint32_t)child[0]);
+                        }
+                        if (v1) {
+                            if (pos1 == 0) cand = child[CPL - 1];
+                            else push_entry(sp + pos1 - 1, (tq_entry)(uint32_t)child[CPL - 1]);
+                        }
+                        sp += nhit - 1;
+                        cur = group_max_i<G>(cand);
+                    } else if (advance()) {
+                        finish();
+                    }
                 } else {
+                    // rank of each of my slots among the four keys of the node (keys of the other lanes come by DPP;
+                    // a key never compares less than itself, so broadcasting all four is fine)
+                    int rank[CPL], nhit = 0;
+                    if (G == 4) {
+                        const uint32_t k0 = (uint32_t)dpp_i<QP_B0>((int)key[0]), k1 = (uint32_t)dpp_i<QP_B1>((int)key[0]);
+                        const uint32_t k2 = (uint32_t)dpp_i<QP_B2>((int)key[0]), k3 = (uint32_t)dpp_i<QP_B3>((int)key[0]);
+                        rank[0] = tq_less(k0, key[0]) + tq_less(k1, key[0]) + tq_less(k2, key[0]) + tq_less(k3, key[0]);
+                        nhit = tq_less(k0, TQ_KEY_INVALID) + tq_less(k1, TQ_KEY_INVALID) + tq_less(k2, TQ_KEY_INVALID) +
+                               tq_less(k3, TQ_KEY_INVALID);
+                    } else if (G == 2) {
+                        const uint32_t p0 = (uint32_t)dpp_i<QP_X1>((int)key[0]), p1 = (uint32_t)dpp_i<QP_X1>((int)key[CPL - 1]);
+                        const int lt01 = tq_less(key[0], key[CPL - 1]);  // my two slots against each other (keys distinct)
+                        rank[0] = (1 - lt01) + tq_less(p0, key[0]) + tq_less(p1, key[0]);
+                        rank[CPL - 1] = lt01 + tq_less(p0, key[CPL - 1]) + tq_less(p1, key[CPL - 1]);
+                        const int mine = tq_less(key[0], TQ_KEY_INVALID) + tq_less(key[CPL - 1], TQ_KEY_INVALID);
+                        nhit = mine + dpp_i<QP_X1>(mine);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < CPL; j++) {
-                        rank[j] = 0;
+                        for (int j = 0; j < CPL; j++) {
+                            rank[j] = 0;
 #pragma unroll
-                        for (int i = 0; i < CPL; i++) rank[j] += tq_less(key[i], key[j]);
-                        nhit += tq_less(key[j], TQ_KEY_INVALID);
+                            for (int i = 0; i < CPL; i++) rank[j] += tq_less(key[i], key[j]);
+                            nhit += tq_less(key[j], TQ_KEY_INVALID);
+                        }
                     }
-                }
-                if (nhit != 0) {
-                    // the nearest child is visited next and never touches the stack; the others are pushed
-                    // far-to-near, so the next nearest ends on top
-                    int32_t cand = CHILD_EMPTY;  // INT_MIN: below every child word
+                    if (nhit != 0) {
+                        // the nearest child is visited next and never touches the stack; the others are pushed
+                        // far-to-near, so the next nearest ends on top
+                        int32_t cand = CHILD_EMPTY;  // INT_MIN: below every child word
 #pragma unroll
-                    for (int j = 0; j < CPL; j++) {
-                        if (rank[j] == 0) cand = child[j];  // rank 0 with nhit != 0 is a hit
-                        if (key[j] != TQ_KEY_INVALID && rank[j] != 0)
-                            push_entry(sp + nhit - 1 - rank[j], ((tq_entry)key[j] << 32) | (tq_entry)(uint32_t)child[j]);
+                        for (int j = 0; j < CPL; j++) {
+                            if (rank[j] == 0) cand = child[j];  // rank 0 with nhit != 0 is a hit
+                            if (key[j] != TQ_KEY_INVALID && rank[j] != 0)
+                                push_entry(sp + nhit - 1 - rank[j], ((tq_entry)key[j] << 32) | (tq_entry)(uint32_t)child[j]);
+                        }
+                        sp += nhit - 1;
+                        cur = group_max_i<G>(cand);
+                    } else if (advance()) {
+                        finish();
                     }
-                    sp += nhit - 1;
-                    cur = group_max_i<G>(cand);
-                } else if (advance()) {
-                    finish();
                 }
             }
         }
