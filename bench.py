@@ -213,7 +213,7 @@ def main():
                                                          "ms_total")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args),
-                         "kernel": "tk::k_trace_group<float,2,false,false,PathIo<float>> (closest hit)", "launches": n_launch,
+                         "kernel": "tk::k_trace_group<float,2,false,false,PathIo<float>,true> (closest hit, pair kernel, compressed nodes)", "launches": n_launch,
                          "avg_launch_ms": avg_ms, "bytes_per_ray": bytes_per_ray,
                          "rays_per_launch": acc["rays_closest"] / n_launch},
         }

@@ -1,13 +1,14 @@
 // tk_kernels.h — the HIP kernels of the wavefront path tracer (gfx950, wave64).
 //
 //   k_generate        camera rays for one batch (src/render.cpp:69-75)
-//   k_trace<false>    closest hit for the extend queue      (scene_intersect,  src/scene.cpp:25)
-//   k_trace<true>     first hit for the shadow queue        (scene_occluded,   src/scene.cpp:49) + radiance add
-//   k_shade           one integrator round per path + wave-aggregated compaction into the next queues
+//   k_trace_group     (tk_trace_quad.h) closest hit for the extend queue (scene_intersect, src/scene.cpp:25), first
+//                     hit for the shadow queue + radiance add (scene_occluded, src/scene.cpp:49), and — with the
+//                     HookIo policy — the C-ABI trace hooks (AoS rays in, hit records out)
+//   k_shade<TAG>      one integrator round per path, one instance per material tag, block-aggregated compaction
+//                     into the next queues
 //   k_sort_*          counting sort of the extend queue by the material tag of the hit
 //   k_accumulate      per-pixel sum of the batch's samples, in sample order (src/render.cpp:68-77)
 //   k_resolve         divide by spp, vertical flip (src/render.cpp:78)
-//   k_trace_rays      the C-ABI trace hooks: AoS rays in, hit records out
 //
 // Launch shape: the trace kernel (tk_trace_quad.h) is persistent (grid = CUs x resident blocks) and pulls work from
 // a device-side head counter, so a round needs no host read-back of the queue length.

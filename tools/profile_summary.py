@@ -69,7 +69,7 @@ key = "false, false, tk::PathIo<float>"  # k_trace_group<float, G, ANY_HIT=false
 fetch, nf = counter_total("fetch", "FETCH_SIZE", key)
 write, nw = counter_total("write", "WRITE_SIZE", key)
 if fetch is not None and nf:
-    t = {"kernel": "tk::k_trace_group<float,2,false,false,PathIo<float>> (closest hit)", "launches": nf,
+    t = {"kernel": "tk::k_trace_group<float,2,false,false,PathIo<float>,true> (closest hit, pair kernel, compressed nodes)", "launches": nf,
          "fetch_bytes_per_launch": fetch * 1024 / nf, "write_bytes_per_launch": (write or 0) * 1024 / max(nw, 1),
          "fetch_bytes_per_launch_x2_corrected": 2 * fetch * 1024 / nf}
     t["hbm_bytes_per_launch"] = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
