@@ -275,8 +275,10 @@ int32_t collapse_to_wide(const std::vector<Bvh2Node> &n2, int root, std::vector<
 // delta = 65535 * step * 2^-21 and then snapped outwards to the grid.  delta pays for the rounding of the grid-space
 // slab test (tk_traverse.h: qray_make); the checks below are on exact values (a float plus a 16-bit multiple of a
 // float is exact in double to ~1e-16 relative, nothing next to delta).
-// Returns the surface-area inflation of the decoded boxes (sum of decoded half-areas / sum of true half-areas):
-// the expected growth in node visits for random rays; the caller keeps the full-width nodes when it is large.
+// Returns the mean over all child boxes of (decoded half-area / true half-area), each ratio capped at 100: how much
+// more often a box is entered by the rays that reach its parent.  (Not weighted by absolute area: a cluster of
+// small primitives inside a huge scene is exactly where the grid is too coarse, and where the camera usually
+// looks.)  The caller keeps the full-width nodes when it is large.
 inline double quantise_nodes(const std::vector<Node4<float>> &in, std::vector<QNode4> &out, float grid_lo[3],
                              float grid_step[3]) {
     out.assign(in.size(), QNode4{});
@@ -304,7 +306,8 @@ inline double quantise_nodes(const std::vector<Node4<float>> &in, std::vector<QN
         }
         grid_lo[a] = p, grid_step[a] = step;
     }
-    double area_true = 0, area_q = 0;
+    double ratio_sum = 0;
+    int64_t n_slots = 0;
     for (size_t n = 0; n < in.size(); n++) {
         const Node4<float> &nd = in[n];
         QNode4 q{};
@@ -324,12 +327,13 @@ inline double quantise_nodes(const std::vector<Node4<float>> &in, std::vector<QN
                 et[a] = (double)nd.c[i].bmax[a] - (double)nd.c[i].bmin[a];
                 eq[a] = (double)(qh - ql) * step;
             }
-            area_true += et[0] * et[1] + et[1] * et[2] + et[2] * et[0];
-            area_q += eq[0] * eq[1] + eq[1] * eq[2] + eq[2] * eq[0];
+            const double at = et[0] * et[1] + et[1] * et[2] + et[2] * et[0], aq = eq[0] * eq[1] + eq[1] * eq[2] + eq[2] * eq[0];
+            ratio_sum += at > 0 ? std::min(aq / at, 100.0) : (aq > 0 ? 100.0 : 1.0);
+            n_slots++;
         }
         out[n] = q;
     }
-    return area_true > 0 ? area_q / area_true : 1.0;
+    return n_slots ? ratio_sum / (double)n_slots : 1.0;
 }
 
 }  // namespace tk

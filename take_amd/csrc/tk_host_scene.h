@@ -18,7 +18,7 @@ template <class R> struct HostScene {
     std::vector<Node4<R>> nodes;
     std::vector<QNode4> qnodes;  // f32: compressed copy of nodes (empty = not in use)
     float grid_lo[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1};
-    double q_inflation = 1.0;    // surface-area inflation of the compressed boxes (1 = none)
+    double q_inflation = 1.0;    // mean surface-area inflation of the compressed child boxes (1 = none)
     std::vector<PrimRec<R>> prims;
     std::vector<PrimShade> prim_shade;
     int32_t root_child = CHILD_EMPTY;
@@ -267,7 +267,7 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
     hs.qnodes.clear();
     if constexpr (sizeof(R) == 4) {
         // f32 scenes traverse the 64-byte compressed nodes unless the 16-bit scene grid is too coarse for the
-        // geometry (boxes growing by more than 10 % in area: a scene mixing scales by >1e4), or on request
+        // geometry (child boxes growing by more than 10 % in area on average: a scene mixing scales by >1e4), or on request
         // (TAKE_HIP_NODES=wide / =q16: A/B runs)
         const char *fmt = std::getenv("TAKE_HIP_NODES");
         const std::string f = fmt ? fmt : "";

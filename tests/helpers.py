@@ -29,6 +29,7 @@ def hostsim():
         L.hostsim_last_error.restype = C.c_char_p
         L.hostsim_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
         L.hostsim_trace.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+        L.hostsim_check_qnodes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         _HOSTSIM = L
     return _HOSTSIM
 

@@ -116,3 +116,42 @@ def test_emissive_mesh_without_normals_is_rejected():
     sd.add_mesh(pos, idx, 0, emission=(1, 1, 1))
     with pytest.raises(RuntimeError, match="no vertex normals"):
         hostsim_render(sd, 0, 1, 1)
+
+
+# ------------------------------------------------------------------ compressed BVH nodes (16-bit scene grid)
+def _check_qnodes(sd):
+    import ctypes as C
+
+    from helpers import hostsim
+
+    out = (C.c_int64 * 5)()
+    desc, keep = sd.to_desc()
+    rc = hostsim().hostsim_check_qnodes(C.byref(desc), out)
+    assert rc == 0, hostsim().hostsim_last_error()
+    return list(out)
+
+
+@pytest.mark.parametrize("name", GOLDEN_SCENES)
+def test_compressed_nodes_contain_the_true_boxes(name):
+    """every compressed child box (exact arithmetic) contains the true box plus the builder's slack, child words
+    are unchanged, and the f32 golden scenes all use the compressed format"""
+    slots, bad, diff, infl, in_use = _check_qnodes(golden_scene(name))
+    assert bad == 0 and diff == 0
+    if slots:
+        assert in_use == 1 and 1.0 <= infl / 1e6 < 1.10
+
+
+def test_compressed_nodes_on_a_large_soup_and_scale_mixing_fallback():
+    slots, bad, diff, infl, in_use = _check_qnodes(scenes.soup_scene(200_000, 64, 64, spp=1))
+    assert slots > 100_000 and bad == 0 and diff == 0 and in_use == 1
+    assert infl / 1e6 < 1.02  # a 16-bit cell is far below a soup triangle
+    # a scene mixing scales by 1e6 (tiny triangles next to a huge one): the 16-bit grid would inflate the small
+    # boxes many times over, the builder must keep the full-width nodes
+    rng = np.random.default_rng(3)
+    sd = scenes.soup_scene(64, 32, 32, spp=1)
+    tiny = (rng.uniform(-1, 1, (2000, 1, 3)) * 1e-3 + rng.uniform(-1, 1, (2000, 3, 3)) * 1e-6).astype(np.float64)
+    sd.add_mesh(tiny.reshape(-1, 3), np.arange(6000, dtype=np.int32).reshape(-1, 3), 0)
+    big = np.array([[-1e3, -1e3, -5.0], [1e3, -1e3, -5.0], [0.0, 1e3, -5.0]])
+    sd.add_mesh(big, np.array([[0, 1, 2]], np.int32), 0)
+    slots, bad, diff, infl, in_use = _check_qnodes(sd)
+    assert in_use == 0 and infl / 1e6 > 1.10
