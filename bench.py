@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--spp", type=int, default=256, help="samples per pixel per GPU")
     ap.add_argument("--max-depth", type=int, default=50)
     ap.add_argument("--spb", type=int, default=0, help="samples per pixel per batch (0 = auto)")
+    ap.add_argument("--materials", default="diffuse", choices=["diffuse", "mixed"],
+                    help="mixed = round-robin over 7 BSDFs (configs[4]'s divergence stress; not the default workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="640x360x1", help="WxHxSPP of the CPU-baseline sample")
     return ap.parse_args()
@@ -55,7 +57,8 @@ def measured_traffic(args):
     (profiles/r01_traffic.json, written by tools/profile.sh -> tools/profile_summary.py; FETCH_SIZE and WRITE_SIZE
     collected in separate passes).  None when the run is not the default configuration the profile was taken on."""
     path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    default = (args.tris, args.width, args.height, args.spp, args.max_depth, args.spb) == (1_000_000, 1920, 1080, 256, 50, 0)
+    default = (args.tris, args.width, args.height, args.spp, args.max_depth, args.spb, args.materials) == (
+        1_000_000, 1920, 1080, 256, 50, 0, "diffuse")
     if not (default and args.gpus == 1 and os.path.exists(path)):
         return None
     with open(path) as f:
@@ -87,7 +90,7 @@ def cpu_baseline(args, sd_full):
 
     w, h, spp = (int(x) for x in args.cpu_sample.split("x"))
     cores = usable_cpus()
-    sd = scenes.soup_scene(args.tris, w, h, spp=spp, max_depth=args.max_depth)
+    sd = scenes.soup_scene(args.tris, w, h, spp=spp, max_depth=args.max_depth, materials=args.materials)
     samples = w * h * spp
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     sample = f"{args.tris}-tri soup, {w}x{h}, {spp} spp, max_depth {args.max_depth}"
@@ -142,7 +145,8 @@ def main():
 
     t0 = time.time()
     spp_total = args.spp * world  # weak scaling: per-GPU samples fixed
-    sd = scenes.soup_scene(args.tris, args.width, args.height, spp=spp_total, max_depth=args.max_depth)
+    sd = scenes.soup_scene(args.tris, args.width, args.height, spp=spp_total, max_depth=args.max_depth,
+                            materials=args.materials)
     scene = capi.Scene(sd, precision=D.TAKE_PRECISION_F32)
     t_setup = time.time() - t0
     stats = scene.stats()
@@ -201,7 +205,7 @@ def main():
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"procedural {args.tris}-triangle soup in 5-wall box + 1 quad area light, "
+            "config": {"workload": f"procedural {args.tris}-triangle soup ({args.materials} materials) in 5-wall box + 1 quad area light, "
                                    f"{args.width}x{args.height}, {args.spp} spp per GPU ({spp_total} total), max_depth "
                                    f"{args.max_depth}, no Russian roulette, constant background (no env-map IBL upstream)",
                        "parallelism": f"tile-row strips over {world} GPU(s), scene replicated, one gather",

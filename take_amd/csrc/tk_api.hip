@@ -93,6 +93,8 @@ template <class R> struct SceneT {
     // render workspace (grown on demand)
     DevBuf<R> state_r;
     DevBuf<int32_t> queue[2], shadow_queue, sorted_queue;
+    DevBuf<uint8_t> sort_keys;            // one key byte per queue entry (material sort)
+    DevBuf<int32_t> sort_hist, sort_base;  // [key][wave] counts and their exclusive scan
     DevBuf<R> accum, out;
     DevBuf<int32_t> qwords;  // Q_NUM_WORDS + 2 * N_SORT_KEYS
     DevBuf<unsigned long long> counters;
@@ -110,7 +112,7 @@ template <class R> struct SceneT {
         nodes.release(), qnodes.release(), prims.release(), prim_shade.release(), shapes.release(), meshes.release(), face_idx.release();
         normals.release(), uvs.release(), texels.release(), materials.release(), images.release(), lights.release();
         state_r.release(), queue[0].release(), queue[1].release(), shadow_queue.release();
-        sorted_queue.release(), accum.release(), out.release(), qwords.release(), counters.release(), spill.release();
+        sorted_queue.release(), sort_keys.release(), sort_hist.release(), sort_base.release(), accum.release(), out.release(), qwords.release(), counters.release(), spill.release();
     }
 };
 
@@ -209,6 +211,7 @@ template <class R> int ensure_workspace(SceneT<R> &sc, int64_t slots, int64_t np
         HIP_TRY(sc.queue[1].alloc(slots));
         HIP_TRY(sc.shadow_queue.alloc(slots));
         HIP_TRY(sc.sorted_queue.alloc(slots));
+        HIP_TRY(sc.sort_keys.alloc(slots));
         sc.capacity = slots;
     }
     if ((int64_t)sc.accum.n < 3 * npix) {
@@ -390,7 +393,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     ts->timed.clear();
     Timer tm{ts, stream, timing};
     int32_t *q = sc.qwords.p;
-    int32_t *tag_count = q + Q_NUM_WORDS, *tag_cursor = q + Q_NUM_WORDS + N_SORT_KEYS;
+    int32_t *tag_count = q + Q_NUM_WORDS;
     QuadSpill spill{sc.spill.p, sc.spill_stride};
     const PathIo<R> io_ext0{st, sc.queue[0].p, rp.ray_eps}, io_ext1{st, sc.queue[1].p, rp.ray_eps};
     const PathIo<R> io_shadow{st, sc.shadow_queue.p, rp.ray_eps};
@@ -398,6 +401,13 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     const int wide_grid = (int)std::min<int64_t>((slots + BLOCK - 1) / BLOCK, (int64_t)ts->num_cus * 8);
     const int pix_grid = (int)std::min<int64_t>((npix + BLOCK - 1) / BLOCK, (int64_t)ts->num_cus * 8);
 
+    if (sort_materials) {
+        const size_t need = (size_t)N_SORT_KEYS * wide_grid * (BLOCK / WAVE);
+        if (sc.sort_hist.n != need) {
+            HIP_TRY(sc.sort_hist.alloc(need));
+            HIP_TRY(sc.sort_base.alloc(need));
+        }
+    }
     HIP_TRY(hipMemsetAsync(sc.accum.p, 0, sizeof(R) * 3 * npix, stream));
     HIP_TRY(hipMemsetAsync(sc.counters.p, 0, sc.counters.bytes(), stream));
     hipEvent_t ev_begin = ts->events.get(), ev_end = ts->events.get();
@@ -426,10 +436,12 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
             const int32_t *shade_in = sc.queue[cur].p;
             if (sort_materials) {
                 tm.begin(TK_OTHER);
-                hipLaunchKernelGGL((k_sort_count<R>), dim3(wide_grid), dim3(BLOCK), 0, stream, sc.dev, st,
-                                   sc.queue[cur].p, n_cur, tag_count);
-                hipLaunchKernelGGL((k_sort_scatter<R>), dim3(wide_grid), dim3(BLOCK), 0, stream, sc.dev, st,
-                                   sc.queue[cur].p, n_cur, tag_count, tag_cursor, sc.sorted_queue.p);
+                hipLaunchKernelGGL((k_sort_count<R>), dim3(wide_grid), dim3(BLOCK), 0, stream, st, sc.queue[cur].p, n_cur,
+                                   sc.sort_keys.p, sc.sort_hist.p);
+                hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(SORT_SCAN_THREADS), 0, stream, sc.sort_hist.p,
+                                   sc.sort_base.p, tag_count, wide_grid * (BLOCK / WAVE));
+                hipLaunchKernelGGL(k_sort_scatter, dim3(wide_grid), dim3(BLOCK), 0, stream, sc.queue[cur].p, n_cur,
+                                   sc.sort_keys.p, sc.sort_base.p, sc.sorted_queue.p);
                 tm.end();
                 shade_in = sc.sorted_queue.p;
             }
@@ -521,7 +533,7 @@ int trace_impl(TakeScene *ts, const void *d_rays, int64_t n, void *d_hits, int32
     ts->events.reset();
     a = ts->events.get(), b = ts->events.get();
     HIP_TRY(hipEventRecord(a, stream));
-    const HookIo<R> io{(const RayAoS<R> *)d_rays, (HitAoS<R> *)d_hits, d_occ};
+    const HookIo<R> io{sc.dev.prims, (const RayAoS<R> *)d_rays, (HitAoS<R> *)d_hits, d_occ};
     launch_trace<R>(sc.group, any, count, dim3(sc.trace_grid), stream, sc.dev, io, nullptr, (int32_t)n, q + Q_HEAD_CLOSEST,
                     sc.counters.p, -1, spill);
     HIP_TRY(hipEventRecord(b, stream));

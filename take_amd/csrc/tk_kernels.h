@@ -101,62 +101,100 @@ k_shade(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, const int32_t *_
     if (want_s) shadow_queue[off_s + mask_rank(ms)] = slot;
 }
 
-// ---- material sort of the extend queue (after trace_closest, before shade): counting sort on the tag of the
-// hit primitive (PrimRec::meta >> 8; misses sort last).  tag_count/tag_cursor: TAKE_MAT_COUNT + 1 words each.
-constexpr int N_SORT_KEYS = 13;
-template <class R> __device__ __forceinline__ int sort_key(const DeviceScene<R> &sc, const PathState<R> &st, int32_t slot) {
-    const int32_t prim = st.I_(S_HIT, slot);
-    return prim < 0 ? N_SORT_KEYS - 1 : ((sc.prims[prim].meta >> 8) & 0xff);
+// ---- material sort of the extend queue (after trace_closest, before shade): a stable counting sort on the tag of
+// the hit primitive (carried in the hit word of the path record; misses sort last), with no atomics at all —
+// the first version's per-wave atomics on 13 cursor words cost 39 % of a mixed-material step.
+//   k_sort_count    every WAVE owns a contiguous range of the queue: it reads the hit words, writes one key byte
+//                   per entry and counts each key with ballots; hist[key][wave]
+//   k_sort_scan     one block: exclusive scan of hist in (key, wave) order -> base[key][wave]; tag_count[key]
+//   k_sort_scatter  same ranges: position = base[key][wave] + entries of that key seen so far in the wave
+// The sorted order is deterministic (ranges and ranks do not depend on timing).
+constexpr int N_SORT_KEYS = TAKE_MAT_COUNT + 1;
+constexpr int SORT_SCAN_THREADS = 1024;
+template <class R> __device__ __forceinline__ int sort_key(const PathState<R> &st, int32_t slot) {
+    const int32_t w = st.I_(S_HIT, slot);
+    return w < 0 ? N_SORT_KEYS - 1 : hit_word_tag(w);
+}
+// range of queue entries owned by global wave `w` of `n_waves`: multiples of 64, contiguous, covering [0, n)
+__device__ __forceinline__ void sort_range(int32_t n, int32_t w, int32_t n_waves, int32_t &begin, int32_t &end) {
+    const int32_t per = ((n + n_waves - 1) / n_waves + WAVE - 1) / WAVE * WAVE;
+    const int64_t b = (int64_t)w * per;
+    begin = (int32_t)(b < n ? b : n);
+    end = (int32_t)(b + per < n ? b + per : n);
 }
 template <class R>
 __global__ void __launch_bounds__(BLOCK)
-k_sort_count(DeviceScene<R> sc, PathState<R> st, const int32_t *__restrict__ queue, const int32_t *__restrict__ n_ptr,
-             int32_t *tag_count) {
-    __shared__ int32_t s_cnt[N_SORT_KEYS];
-    if (threadIdx.x < N_SORT_KEYS) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const int32_t n = *n_ptr;
-    for (int32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
-        atomicAdd(&s_cnt[sort_key(sc, st, queue[i])], 1);
-    __syncthreads();
-    if (threadIdx.x < N_SORT_KEYS && s_cnt[threadIdx.x]) atomicAdd(&tag_count[threadIdx.x], s_cnt[threadIdx.x]);
-}
-template <class R>
-__global__ void __launch_bounds__(BLOCK)
-k_sort_scatter(DeviceScene<R> sc, PathState<R> st, const int32_t *__restrict__ queue,
-               const int32_t *__restrict__ n_ptr, const int32_t *__restrict__ tag_count, int32_t *tag_cursor,
-               int32_t *sorted) {
-    const int32_t n = *n_ptr;
-    int32_t basek[N_SORT_KEYS];
-    int32_t acc = 0;
+k_sort_count(PathState<R> st, const int32_t *__restrict__ queue, const int32_t *__restrict__ n_ptr, uint8_t *keys,
+             int32_t *hist) {
+    const int32_t n = *n_ptr, n_waves = gridDim.x * (BLOCK / WAVE);
+    const int32_t w = blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+    int32_t begin, end;
+    sort_range(n, w, n_waves, begin, end);
+    int32_t cnt[N_SORT_KEYS];
 #pragma unroll
-    for (int t = 0; t < N_SORT_KEYS; t++) {
-        basek[t] = acc;
-        acc += tag_count[t];
+    for (int t = 0; t < N_SORT_KEYS; t++) cnt[t] = 0;
+    for (int32_t i = begin + lane_id(); i < end + lane_id(); i += WAVE) {  // uniform trip count
+        const bool valid = i < end;
+        const int key = valid ? sort_key(st, queue[i]) : -1;
+        if (valid) keys[i] = (uint8_t)key;
+#pragma unroll
+        for (int t = 0; t < N_SORT_KEYS; t++) cnt[t] += (int32_t)__popcll(__ballot(key == t));
     }
-    const int32_t n_round = (n + WAVE - 1) / WAVE * WAVE;
-    for (int32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += gridDim.x * BLOCK) {
-        const bool valid = i < n;
-        const int32_t slot = valid ? queue[i] : 0;
-        const int key = valid ? sort_key(sc, st, slot) : -1;
-        // one aggregated append per tag present in the wave
-        uint64_t todo = __ballot(valid);
-        while (todo) {
-            const int leader = __ffsll((unsigned long long)todo) - 1;
-            const int kk = __shfl(key, leader);
-            const bool mine = valid && key == kk;
-            const uint64_t m = __ballot(mine);
-            int32_t base = 0;
-            if (lane_id() == leader) base = atomicAdd(&tag_cursor[kk], (int32_t)__popcll(m));
-            base = __shfl(base, leader);
-            if (mine) {
-                int32_t b = 0;
+    int32_t mine = 0;
 #pragma unroll
-                for (int t = 0; t < N_SORT_KEYS; t++) b = (t == kk) ? basek[t] : b;
-                sorted[b + base + mask_rank(m)] = slot;
-            }
-            todo &= ~m;
+    for (int t = 0; t < N_SORT_KEYS; t++) mine = lane_id() == t ? cnt[t] : mine;
+    if (lane_id() < N_SORT_KEYS) hist[lane_id() * n_waves + w] = mine;
+}
+__global__ void __launch_bounds__(SORT_SCAN_THREADS)
+k_sort_scan(const int32_t *__restrict__ hist, int32_t *base, int32_t *tag_count, int32_t n_waves) {
+    __shared__ int32_t s_sum[SORT_SCAN_THREADS];
+    const int32_t total = N_SORT_KEYS * n_waves;
+    const int32_t per = (total + SORT_SCAN_THREADS - 1) / SORT_SCAN_THREADS;
+    const int32_t lo = min((int32_t)threadIdx.x * per, total), hi = min(lo + per, total);
+    int32_t sum = 0;
+    for (int32_t i = lo; i < hi; i++) sum += hist[i];
+    s_sum[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < SORT_SCAN_THREADS; off <<= 1) {  // Hillis-Steele inclusive scan of the per-thread sums
+        const int32_t v = threadIdx.x >= off ? s_sum[threadIdx.x - off] : 0;
+        __syncthreads();
+        s_sum[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int32_t run = s_sum[threadIdx.x] - sum;  // exclusive prefix of this thread's run
+    for (int32_t i = lo; i < hi; i++) {
+        base[i] = run;
+        run += hist[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < N_SORT_KEYS) {  // totals per key = base of the next key's first wave - base of this key's
+        const int32_t first = threadIdx.x * n_waves, next = first + n_waves;
+        const int32_t end = next < total ? base[next] : s_sum[SORT_SCAN_THREADS - 1];
+        tag_count[threadIdx.x] = end - base[first];
+    }
+}
+__global__ void __launch_bounds__(BLOCK)
+k_sort_scatter(const int32_t *__restrict__ queue, const int32_t *__restrict__ n_ptr, const uint8_t *__restrict__ keys,
+               const int32_t *__restrict__ base, int32_t *sorted) {
+    const int32_t n = *n_ptr, n_waves = gridDim.x * (BLOCK / WAVE);
+    const int32_t w = blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+    int32_t begin, end;
+    sort_range(n, w, n_waves, begin, end);
+    if (begin >= end) return;
+    int32_t off[N_SORT_KEYS];
+#pragma unroll
+    for (int t = 0; t < N_SORT_KEYS; t++) off[t] = base[t * n_waves + w];
+    for (int32_t i = begin + lane_id(); i < end + lane_id(); i += WAVE) {
+        const bool valid = i < end;
+        const int key = valid ? (int)keys[i] : -1;
+        int32_t pos = 0;
+#pragma unroll
+        for (int t = 0; t < N_SORT_KEYS; t++) {
+            const uint64_t m = __ballot(key == t);
+            if (key == t) pos = off[t] + mask_rank(m);
+            off[t] += (int32_t)__popcll(m);
         }
+        if (valid) sorted[pos] = queue[i];
     }
 }
 
