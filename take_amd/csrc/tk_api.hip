@@ -395,8 +395,8 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     int32_t *q = sc.qwords.p;
     int32_t *tag_count = q + Q_NUM_WORDS;
     QuadSpill spill{sc.spill.p, sc.spill_stride};
-    const PathIo<R> io_ext0{st, sc.queue[0].p, rp.ray_eps}, io_ext1{st, sc.queue[1].p, rp.ray_eps};
-    const PathIo<R> io_shadow{st, sc.shadow_queue.p, rp.ray_eps};
+    const PathIo<R> io_ext0{sc.dev.prims, st, sc.queue[0].p, rp.ray_eps}, io_ext1{sc.dev.prims, st, sc.queue[1].p, rp.ray_eps};
+    const PathIo<R> io_shadow{sc.dev.prims, st, sc.shadow_queue.p, rp.ray_eps};
     const dim3 tgrid(sc.trace_grid);
     const int wide_grid = (int)std::min<int64_t>((slots + BLOCK - 1) / BLOCK, (int64_t)ts->num_cus * 8);
     const int pix_grid = (int)std::min<int64_t>((npix + BLOCK - 1) / BLOCK, (int64_t)ts->num_cus * 8);

@@ -88,15 +88,16 @@ __device__ __noinline__ void tq_spill_store(tq_entry *p, tq_entry e) { *p = e; }
 __device__ __noinline__ tq_entry tq_spill_load(const tq_entry *p) { return *p; }
 
 // IO policies: where rays come from and where results go.
-//   load(i, ray, tag): ray i of the work list;  store_hit(tag, prim, meta, t, u, v) / store_occlusion(tag, occ):
+//   load(i, ray, tag): ray i of the work list;  store_hit(tag, prim, t, u, v) / store_occlusion(tag, occ):
 //   called by ONE lane of the group.
 template <class R> struct PathIo {  // the render loop: rays in the path state, indexed through a queue
+    const PrimRec<R> *prims;
     PathState<R> st;
     const int32_t *queue;
     R eps;
-    template <bool SHADOW> __device__ __forceinline__ void load(int32_t i, RayT<R> &ray, int64_t &tag) const {
+    template <bool SHADOW> __device__ __forceinline__ void load(int32_t i, RayT<R> &ray, int32_t &tag) const {
         const int64_t slot = queue[i];
-        tag = slot;
+        tag = (int32_t)slot;
         if (!SHADOW)
             ray = make_ray(st.R_(S_OX, slot), st.R_(S_OY, slot), st.R_(S_OZ, slot), st.R_(S_DX, slot), st.R_(S_DY, slot),
                            st.R_(S_DZ, slot), eps, Const<R>::inf());
@@ -104,8 +105,9 @@ template <class R> struct PathIo {  // the render loop: rays in the path state, 
             ray = make_ray(st.R_(S_OX, slot), st.R_(S_OY, slot), st.R_(S_OZ, slot), st.R_(S_SX, slot), st.R_(S_SY, slot),
                            st.R_(S_SZ, slot), eps, st.R_(S_ST, slot));
     }
-    __device__ __forceinline__ void store_hit(int64_t slot, int32_t prim, int32_t meta, R t, R u, R v) const {
-        st.I_(S_HIT, slot) = hit_word(prim, meta);
+    // (the primitive's meta is re-read here, once per ray, rather than kept in a register through the traversal)
+    __device__ __forceinline__ void store_hit(int64_t slot, int32_t prim, R t, R u, R v) const {
+        st.I_(S_HIT, slot) = prim >= 0 ? hit_word(prim, prims[prim].meta) : -1;
         st.R_(S_HT, slot) = t;
         st.R_(S_HU, slot) = u;
         st.R_(S_HV, slot) = v;
@@ -135,12 +137,12 @@ template <class R> struct HookIo {  // the C-ABI trace hooks: AoS rays in, hit r
     const RayAoS<R> *rays;
     HitAoS<R> *hits;
     int32_t *occluded;
-    template <bool SHADOW> __device__ __forceinline__ void load(int32_t i, RayT<R> &ray, int64_t &tag) const {
+    template <bool SHADOW> __device__ __forceinline__ void load(int32_t i, RayT<R> &ray, int32_t &tag) const {
         const RayAoS<R> q = rays[i];
         tag = i;
         ray = make_ray(q.org[0], q.org[1], q.org[2], q.dir[0], q.dir[1], q.dir[2], q.tmin, q.tmax);
     }
-    __device__ __forceinline__ void store_hit(int64_t i, int32_t prim, int32_t meta, R t, R u, R v) const {
+    __device__ __forceinline__ void store_hit(int64_t i, int32_t prim, R t, R u, R v) const {
         HitAoS<R> h{};
         h.shape_id = prim >= 0 ? prims[prim].shape_id : -1;
         h.t = prim >= 0 ? t : R(0);
@@ -202,12 +204,12 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
     RayT<R> ray{};
     R idx = R(0), idy = R(0), idz = R(0), tbest = R(0);
     QRay qr{};  // QN: the ray in grid space (replaces idx/idy/idz, which are dead then)
-    int64_t tag = 0;
+    int32_t tag = 0;            // path slot (render) / ray index (trace hooks) of the ray in this slot
     int sp = 0;                 // entries on this group's stack
     int32_t cur = CHILD_EMPTY;  // >= 0: at an interior node; < 0: at a leaf; CHILD_EMPTY: the slot holds no ray
     // per-lane best candidate (differs between the lanes of a group)
     R my_t = Const<R>::inf(), my_u = R(0), my_v = R(0);
-    int32_t my_prim = -1, my_meta = 0;
+    int32_t my_prim = -1;
     uint32_t cnt_nodes = 0, cnt_prims = 0, cnt_leaves = 0, cnt_wnode = 0, cnt_wleaf = 0, cnt_wait = 0, cnt_idle = 0;
 
     // The trace kernels are bound by VALU issue (profiles/): stack addressing uses 24-bit multiplies
@@ -243,9 +245,9 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
             // the lane holding the closest candidate writes it (highest lane on an exact tie)
             const int win = group_max_i<G>((my_prim >= 0 && my_t == tbest) ? gl : -1);
             if (win < 0) {
-                if (gl == 0) io.store_hit(tag, -1, 0, ray.tmax, R(0), R(0));
+                if (gl == 0) io.store_hit(tag, -1, ray.tmax, R(0), R(0));
             } else if (gl == win) {
-                io.store_hit(tag, my_prim, my_meta, my_t, my_u, my_v);
+                io.store_hit(tag, my_prim, my_t, my_u, my_v);
             }
         }
         cur = CHILD_EMPTY;
@@ -284,7 +286,6 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                         sp = 0;
                         my_t = Const<R>::inf();
                         my_prim = -1;
-                        my_meta = 0;
                         my_u = my_v = R(0);
                         cur = sc.root_child;
                         if (sc.root_child == CHILD_EMPTY) finish();  // empty scene: a miss, the slot stays idle
@@ -434,7 +435,6 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                     if (ok) {
                         my_t = t, my_u = u, my_v = v;
                         my_prim = first + k;
-                        my_meta = p.meta;
                     }
                 }
                 tbest = tk_fmin(tbest, group_min<G>(my_t));
