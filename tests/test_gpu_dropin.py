@@ -1,0 +1,65 @@
+"""The drop-in, end to end: oracle/_ref/take_gpu is the reference's OWN main.cpp + XML/PLY parsers + imwrite, with
+src/render.cpp replaced by take_amd/host/render_hip.cpp (the patch of INTEGRATION.md) and linked to
+libtake_hip.so.  It is built in the authoring container by `make -C oracle gpu_cli` (reference sources stay where
+they are) and travels to the GPU box as a binary.  Run on the golden XML scenes it must give exactly the image the
+C ABI gives for the flattened scene, and leave the reference's `image.exr` behind."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import GOLD, golden_scene
+from take_amd import capi
+from take_amd import cdefs as D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "oracle", "_ref", "take_gpu")
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = map(int, f.readline().split())
+        assert float(f.readline()) < 0  # little endian
+        return np.frombuffer(f.read(), "<f4").reshape(h, w, 3)  # the reference writes Image3 order: row 0 = top
+
+
+def run_cli(scene_xml, cwd, max_depth, env_extra):
+    env = dict(os.environ, **env_extra)
+    return subprocess.run([CLI, scene_xml, "-max_depth", str(max_depth)], cwd=cwd, env=env, capture_output=True,
+                          text=True, timeout=300)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cbox", "mats", "spherelight"])
+def test_reference_cli_with_gpu_render_matches_c_abi(name, tmp_path):
+    if not os.path.exists(CLI):
+        pytest.skip("oracle/_ref/take_gpu was not built (needs the reference sources: authoring container)")
+    pfm = str(tmp_path / "out.pfm")
+    r = run_cli(os.path.join(GOLD, "scenes", name + ".xml"), str(tmp_path), 5, {"TAKE_HIP_DUMP_PFM": pfm, "TAKE_HIP_SEED": "7"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    for phrase in ("Parsing and constructing scene", "Building BVH...", "Rendering...", "Finish building rendering."):
+        assert phrase in r.stdout  # the reference's own progress messages (src/render.cpp:25-29,48-50,58,83)
+    exr = tmp_path / "image.exr"  # written by the reference's main.cpp:22 through its imwrite
+    assert exr.exists() and exr.read_bytes()[:4] == bytes([0x76, 0x2F, 0x31, 0x01])
+    got = read_pfm(pfm)
+    sd = golden_scene(name)
+    sc = capi.Scene(sd, precision=D.TAKE_PRECISION_F32)
+    want = sc.render(spp=sd.spp, max_depth=5, seed=7)
+    sc.close()
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_reference_cli_without_gpu_fails_like_the_parser_does():
+    """no HIP device: the library has no CPU path; the error leaves as the reference's exception type"""
+    if not os.path.exists(CLI):
+        pytest.skip("oracle/_ref/take_gpu was not built")
+    try:
+        capi.device_count()
+        pytest.skip("a GPU is visible")
+    except capi.TakeError:
+        pass  # no HIP device: the case under test
+    r = run_cli(os.path.join(GOLD, "scenes", "cbox.xml"), "/tmp", 5, {})
+    assert r.returncode != 0
+    assert "fl_exception" in r.stderr and "no HIP device" in r.stderr
