@@ -96,12 +96,13 @@ def debug_table(name, inp, rnd, precision=D.TAKE_PRECISION_F64):
 class Scene:
     """A scene resident on the current HIP device: flattened `Scene` + wide BVH in HBM."""
 
-    def __init__(self, scene_data, precision=D.TAKE_PRECISION_F32, bvh_threads=0, max_leaf_size=0):
+    def __init__(self, scene_data, precision=D.TAKE_PRECISION_F32, bvh_threads=0, max_leaf_size=0,
+                 builder=D.TAKE_BUILDER_HOST_SAH):
         self.sd = scene_data
         self.precision = precision
         self.dtype = np.float64 if precision == D.TAKE_PRECISION_F64 else np.float32
         desc, keep = scene_data.to_desc()
-        opts = D.TakeBuildOpts(precision, bvh_threads, max_leaf_size, 0)
+        opts = D.TakeBuildOpts(precision, bvh_threads, max_leaf_size, builder)
         h = C.c_void_p()
         _check(lib().take_hip_scene_create(C.byref(desc), C.byref(opts), C.byref(h)))
         self.h = h

@@ -58,7 +58,11 @@ class TakeSceneDesc(C.Structure):
 
 class TakeBuildOpts(C.Structure):
     _fields_ = [("precision", C.c_int32), ("bvh_threads", C.c_int32), ("max_leaf_size", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("builder", C.c_int32)]
+
+
+TAKE_BUILDER_HOST_SAH = 0
+TAKE_BUILDER_DEVICE_LBVH = 1
 
 
 class TakeRenderOpts(C.Structure):

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <string>
 #include <thread>
@@ -15,6 +16,7 @@
 
 #include "take_hip.h"
 #include "tk_host_scene.h"
+#include "tk_build_gpu.h"
 #include "tk_kernels.h"
 
 using namespace tk;
@@ -102,6 +104,7 @@ template <class R> struct SceneT {
     int64_t capacity = 0;  // path slots allocated
     int trace_grid = 0;
     int group = 4;             // lanes per ray of the trace kernel
+    bool built_on_device = false;
     int64_t spill_stride = 0;  // ray groups in the persistent trace grid
 
     size_t scene_bytes() const {
@@ -136,23 +139,167 @@ template <class R> SceneT<R> &pick(TakeScene *s);
 template <> SceneT<float> &pick<float>(TakeScene *s) { return s->f; }
 template <> SceneT<double> &pick<double>(TakeScene *s) { return s->d; }
 
+// BVH build on the device (tk_build_gpu.h).  In: sc.prims / sc.prim_shade uploaded in SHAPE order.  Out: both in
+// leaf order, sc.nodes or sc.qnodes, host-side stats and grid.  Returns TAKE_OK, an error, or 1 = "use the host
+// builder" (tree deeper than the traversal stack allows: long runs of equal Morton codes).
+int build_bvh_device(SceneT<float> &sc, int max_leaf, bool compressed_ok, bool compressed_forced) {
+    using namespace lbvh;
+    HostScene<float> &h = sc.host;
+    const int n = (int)sc.prims.n;
+    const int leaf_size = std::max(1, std::min(max_leaf > 0 ? max_leaf : 2, MAX_LEAF));
+    const int n_leaves = (n + leaf_size - 1) / leaf_size;
+    if (n_leaves < 2) return 1;
+    hipStream_t stream = nullptr;
+    const dim3 blk(BLK);
+    auto grid = [](int64_t items) { return dim3((unsigned)((items + BLK - 1) / BLK)); };
+
+    DevBuf<Box> pb, lbox, ibox;
+    DevBuf<uint32_t> keys, vals, keys_s, vals_s, lkey;
+    DevBuf<int> scene_ord, parent_i, parent_l, flag, frontier[2], lvl;
+    DevBuf<int2> child;
+    DevBuf<char> temp;
+    DevBuf<double> acc;
+    struct Cleanup {
+        std::function<void()> f;
+        ~Cleanup() { f(); }
+    } cleanup{[&] {
+        pb.release(), lbox.release(), ibox.release(), keys.release(), vals.release(), keys_s.release(), vals_s.release();
+        lkey.release(), scene_ord.release(), parent_i.release(), parent_l.release(), flag.release();
+        frontier[0].release(), frontier[1].release(), lvl.release(), child.release(), temp.release(), acc.release();
+    }};
+    HIP_TRY(pb.alloc(n));
+    HIP_TRY(keys.alloc(n));
+    HIP_TRY(vals.alloc(n));
+    HIP_TRY(keys_s.alloc(n));
+    HIP_TRY(vals_s.alloc(n));
+    HIP_TRY(scene_ord.alloc(6));
+    const int ord_init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
+    HIP_TRY(hipMemcpy(scene_ord.p, ord_init, sizeof(ord_init), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_prim_boxes, grid(n), blk, 0, stream, sc.prims.p, n, pb.p, scene_ord.p);
+    hipLaunchKernelGGL(k_morton, grid(n), blk, 0, stream, pb.p, n, scene_ord.p, keys.p, vals.p);
+    size_t temp_bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n, 0, 30, stream));
+    HIP_TRY(temp.alloc(temp_bytes));
+    HIP_TRY(rocprim::radix_sort_pairs(temp.p, temp_bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n, 0, 30, stream));
+
+    HIP_TRY(lbox.alloc(n_leaves));
+    HIP_TRY(lkey.alloc(n_leaves));
+    HIP_TRY(ibox.alloc(n_leaves));
+    HIP_TRY(child.alloc(n_leaves));
+    HIP_TRY(parent_i.alloc(n_leaves));
+    HIP_TRY(parent_l.alloc(n_leaves));
+    HIP_TRY(flag.alloc(n_leaves));
+    HIP_TRY(hipMemsetAsync(flag.p, 0, flag.bytes(), stream));
+    hipLaunchKernelGGL(k_leaves, grid(n_leaves), blk, 0, stream, pb.p, keys_s.p, vals_s.p, n, leaf_size, n_leaves, lbox.p, lkey.p);
+    hipLaunchKernelGGL(k_hierarchy, grid(n_leaves - 1), blk, 0, stream, lkey.p, n_leaves, child.p, parent_i.p, parent_l.p);
+    hipLaunchKernelGGL(k_refit, grid(n_leaves), blk, 0, stream, n_leaves, child.p, parent_i.p, parent_l.p, lbox.p, ibox.p, flag.p);
+
+    // collapse to 4-wide nodes, breadth-first, one launch per level
+    HIP_TRY(sc.nodes.alloc(n_leaves));
+    HIP_TRY(frontier[0].alloc(n_leaves));
+    HIP_TRY(frontier[1].alloc(n_leaves));
+    HIP_TRY(lvl.alloc(MAX_LEVELS + 2));
+    HIP_TRY(hipMemsetAsync(lvl.p, 0, lvl.bytes(), stream));
+    hipLaunchKernelGGL(k_fill_int, dim3(1), blk, 0, stream, lvl.p, 1, 1);           // one node on level 0 ...
+    hipLaunchKernelGGL(k_fill_int, dim3(1), blk, 0, stream, frontier[0].p, 1, 0);   // ... made from BVH2 node 0
+    const int cgrid = std::max(1, std::min((n_leaves + BLK - 1) / BLK, 2048));
+    for (int level = 0; level < MAX_LEVELS; level++)
+        hipLaunchKernelGGL(k_collapse, dim3(cgrid), blk, 0, stream, level, frontier[level & 1].p, frontier[(level + 1) & 1].p,
+                           lvl.p, child.p, ibox.p, lbox.p, leaf_size, n, sc.nodes.p);
+    int lvl_h[MAX_LEVELS + 2];
+    int ord_h[6];
+    HIP_TRY(hipMemcpyAsync(lvl_h, lvl.p, sizeof(lvl_h), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(ord_h, scene_ord.p, sizeof(ord_h), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (lvl_h[MAX_LEVELS] != 0) {
+        sc.nodes.release();
+        return 1;  // deeper than the traversal stack allows
+    }
+    int64_t n_nodes = 0;
+    int depth = 0;
+    for (int k = 0; k < MAX_LEVELS; k++)
+        if (lvl_h[k] > 0) n_nodes += lvl_h[k], depth = k + 1;
+    h.stats = WideBvhStats{};
+    h.stats.n_nodes = n_nodes, h.stats.n_prims = n, h.stats.depth = depth;
+    h.root_child = 0;
+    sc.nodes.n = (size_t)n_nodes;  // the tail of the allocation is unused
+
+    // compressed nodes on the scene grid (same fall-back rule as the host path)
+    h.q_inflation = 1.0;
+    bool use_q = false;
+    if (compressed_ok) {
+        double lo[3], hi[3];
+        for (int a = 0; a < 3; a++) lo[a] = ord2f(ord_h[a]), hi[a] = ord2f(ord_h[3 + a]);
+        const Grid g = make_grid(lo, hi);
+        HIP_TRY(sc.qnodes.alloc((size_t)n_nodes));
+        HIP_TRY(acc.alloc(2));
+        HIP_TRY(hipMemsetAsync(acc.p, 0, acc.bytes(), stream));
+        hipLaunchKernelGGL(k_quantise, grid(n_nodes), blk, 0, stream, sc.nodes.p, (int)n_nodes, g, sc.qnodes.p, acc.p);
+        double acc_h[2] = {0, 0};
+        HIP_TRY(hipMemcpy(acc_h, acc.p, sizeof(acc_h), hipMemcpyDeviceToHost));
+        h.q_inflation = acc_h[1] > 0 ? acc_h[0] / acc_h[1] : 1.0;
+        use_q = compressed_forced || h.q_inflation <= 1.10;
+        for (int a = 0; a < 3; a++) h.grid_lo[a] = g.lo[a], h.grid_step[a] = g.step[a];
+        if (use_q) sc.nodes.release();
+        else sc.qnodes.release();
+    }
+    // records into leaf order
+    DevBuf<PrimRec<float>> prims_sorted;
+    DevBuf<PrimShade> shade_sorted;
+    HIP_TRY(prims_sorted.alloc(n));
+    HIP_TRY(shade_sorted.alloc(n));
+    hipLaunchKernelGGL((k_permute<PrimRec<float>>), grid(n), blk, 0, stream, sc.prims.p, vals_s.p, n, prims_sorted.p);
+    hipLaunchKernelGGL((k_permute<PrimShade>), grid(n), blk, 0, stream, sc.prim_shade.p, vals_s.p, n, shade_sorted.p);
+    HIP_TRY(hipStreamSynchronize(stream));
+    sc.prims.release(), sc.prim_shade.release();
+    sc.prims = prims_sorted, sc.prim_shade = shade_sorted;  // DevBuf is a plain handle: ownership moves
+    HIP_TRY(hipGetLastError());
+    return TAKE_OK;
+}
+template <class R> int build_bvh_device_any(SceneT<R> &sc, int max_leaf, bool compressed_ok, bool compressed_forced) {
+    if constexpr (sizeof(R) == 4) return build_bvh_device(sc, max_leaf, compressed_ok, compressed_forced);
+    return 1;
+}
+
 template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, const TakeBuildOpts &opts) {
     SceneT<R> &sc = pick<R>(ts);
     int threads = opts.bvh_threads > 0 ? opts.bvh_threads : (int)std::thread::hardware_concurrency();
     if (threads <= 0) threads = 1;
     int max_leaf = opts.max_leaf_size;
     if (max_leaf <= 0 && std::getenv("TAKE_HIP_MAX_LEAF")) max_leaf = std::atoi(std::getenv("TAKE_HIP_MAX_LEAF"));  // tuning knob
-    std::string err = prepare_scene<R>(desc, max_leaf, threads, sc.host);
-    if (!err.empty()) return fail(TAKE_E_INVALID, err);
-    const HostScene<R> &h = sc.host;
     sc.group = 2;  // pair traversal: measured fastest on MI355X (profiles/)
     if (const char *g = std::getenv("TAKE_HIP_GROUP")) sc.group = std::atoi(g);  // tuning knob: lanes per ray (1, 2, 4)
     if (sc.group != 1 && sc.group != 4) sc.group = 2;
-    const bool use_q = sc.group == 2 && !h.qnodes.empty();  // compressed nodes: f32 pair kernel
-    if (use_q) HIP_TRY(sc.qnodes.upload(h.qnodes));
-    else HIP_TRY(sc.nodes.upload(h.nodes));
+    const char *fmt_env = std::getenv("TAKE_HIP_NODES");
+    const std::string fmt = fmt_env ? fmt_env : "";
+    // device build: f32 scenes with enough primitives to make a tree; otherwise (and as its fall-back) the host SAH build
+    bool on_device = opts.builder == TAKE_BUILDER_DEVICE_LBVH && sizeof(R) == 4 && desc.n_shapes >= 8;
+    std::string err = prepare_scene<R>(desc, max_leaf, threads, sc.host, !on_device);
+    if (!err.empty()) return fail(TAKE_E_INVALID, err);
+    HostScene<R> &h = sc.host;
     HIP_TRY(sc.prims.upload(h.prims));
     HIP_TRY(sc.prim_shade.upload(h.prim_shade));
+    bool use_q = false;
+    if (on_device) {
+        const int rc = build_bvh_device_any<R>(sc, max_leaf, sc.group == 2 && fmt != "wide", fmt == "q16");
+        if (rc == 1) {  // not buildable on the device (tree too deep): do it on the host after all
+            on_device = false;
+            err = prepare_scene<R>(desc, max_leaf, threads, sc.host, true);
+            if (!err.empty()) return fail(TAKE_E_INVALID, err);
+            HIP_TRY(sc.prims.upload(h.prims));
+            HIP_TRY(sc.prim_shade.upload(h.prim_shade));
+        } else if (rc != TAKE_OK) {
+            return rc;
+        } else {
+            use_q = sc.qnodes.p != nullptr;
+        }
+    }
+    if (!on_device) {
+        use_q = sc.group == 2 && !h.qnodes.empty();  // compressed nodes: f32 pair kernel
+        if (use_q) HIP_TRY(sc.qnodes.upload(h.qnodes));
+        else HIP_TRY(sc.nodes.upload(h.nodes));
+    }
+    sc.built_on_device = on_device;
     HIP_TRY(sc.shapes.upload(h.shapes));
     HIP_TRY(sc.meshes.upload(h.meshes));
     HIP_TRY(sc.face_idx.upload(h.face_idx));
@@ -164,6 +311,7 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     HIP_TRY(sc.lights.upload(h.lights));
     DeviceScene<R> &d = sc.dev;
     d = h.view();
+    d.n_nodes = (int32_t)h.stats.n_nodes;
     d.nodes = sc.nodes.p;
     d.qnodes = use_q ? sc.qnodes.p : nullptr;
     d.prims = sc.prims.p;

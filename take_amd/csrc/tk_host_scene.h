@@ -86,7 +86,7 @@ template <class R> inline void make_camera(const TakeCamera &c, CameraRec<R> &ou
 
 // returns "" on success, else an error message (-> TAKE_E_INVALID)
 template <class R>
-std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, HostScene<R> &hs) {
+std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, HostScene<R> &hs, bool build_bvh = true) {
     if (d.camera.width <= 0 || d.camera.height <= 0) return "camera width/height must be positive";
     if (d.n_shapes < 0 || d.n_meshes < 0 || d.n_spheres < 0 || d.n_lights < 0 || d.n_materials < 0 || d.n_images < 0)
         return "negative count in scene description";
@@ -258,23 +258,34 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
         }
     }
 
-    // acceleration structure
-    // default leaf size 2: on triangle soups the tighter leaf boxes save more primitive tests than the extra
-    // interior nodes cost (1M soup: 48.5 node + 10.8 primitive tests per ray vs 42.6 + 42.6 with 4 per leaf)
-    Bvh2Builder builder(bp, max_leaf > 0 ? max_leaf : 2, threads);
-    const int root = builder.build();
+    // acceleration structure (build_bvh == false: the caller builds it on the device from the primitives in shape
+    // order — tk_build_gpu.h — and only the records are prepared here)
     std::vector<int32_t> order;
-    hs.root_child = collapse_to_wide<R>(builder.nodes(), root, hs.nodes, order, hs.stats);
-    hs.qnodes.clear();
-    if constexpr (sizeof(R) == 4) {
-        // f32 scenes traverse the 64-byte compressed nodes unless the 16-bit scene grid is too coarse for the
-        // geometry (child boxes growing by more than 10 % in area on average: a scene mixing scales by >1e4), or on request
-        // (TAKE_HIP_NODES=wide / =q16: A/B runs)
-        const char *fmt = std::getenv("TAKE_HIP_NODES");
-        const std::string f = fmt ? fmt : "";
-        if (f != "wide" && !hs.nodes.empty()) {
-            hs.q_inflation = quantise_nodes(hs.nodes, hs.qnodes, hs.grid_lo, hs.grid_step);
-            if (hs.q_inflation > 1.10 && f != "q16") hs.qnodes.clear();
+    if (!build_bvh) {
+        order.resize(bp.size());
+        for (size_t k = 0; k < order.size(); k++) order[k] = (int32_t)k;
+        hs.nodes.clear();
+        hs.qnodes.clear();
+        hs.root_child = CHILD_EMPTY;
+        hs.stats = WideBvhStats{};
+        hs.stats.n_prims = (int64_t)order.size();
+    } else {
+        // default leaf size 2: on triangle soups the tighter leaf boxes save more primitive tests than the extra
+        // interior nodes cost (1M soup: 48.5 node + 10.8 primitive tests per ray vs 42.6 + 42.6 with 4 per leaf)
+        Bvh2Builder builder(bp, max_leaf > 0 ? max_leaf : 2, threads);
+        const int root = builder.build();
+        hs.root_child = collapse_to_wide<R>(builder.nodes(), root, hs.nodes, order, hs.stats);
+        hs.qnodes.clear();
+        if constexpr (sizeof(R) == 4) {
+            // f32 scenes traverse the 64-byte compressed nodes unless the 16-bit scene grid is too coarse for the
+            // geometry (child boxes growing by more than 10 % in area on average: a scene mixing scales by >1e4), or on request
+            // (TAKE_HIP_NODES=wide / =q16: A/B runs)
+            const char *fmt = std::getenv("TAKE_HIP_NODES");
+            const std::string f = fmt ? fmt : "";
+            if (f != "wide" && !hs.nodes.empty()) {
+                hs.q_inflation = quantise_nodes(hs.nodes, hs.qnodes, hs.grid_lo, hs.grid_step);
+                if (hs.q_inflation > 1.10 && f != "q16") hs.qnodes.clear();
+            }
         }
     }
     hs.prims.resize(order.size());
@@ -292,7 +303,7 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
         }
         hs.prim_shade[k] = ps;
     }
-    if (3 * hs.stats.depth + 1 > 96) return "BVH too deep for the traversal stack";
+    if (3 * hs.stats.depth + 1 > MAX_STACK_ENTRIES) return "BVH too deep for the traversal stack";
     return "";
 }
 

@@ -18,6 +18,7 @@ namespace tk {
 
 constexpr int32_t CHILD_EMPTY = (int32_t)0x80000000;
 constexpr int MAX_LEAF = 4;
+constexpr int MAX_STACK_ENTRIES = 96;  // deepest traversal stack the trace kernels provide (LDS levels + spill area): 3 per tree level + 1
 
 // child word: >= 0 interior node index; < 0 (and != CHILD_EMPTY) leaf: -(1 + first*4 + (count-1))
 TK_HD int32_t make_leaf(int32_t first, int32_t count) { return -(1 + first * MAX_LEAF + (count - 1)); }

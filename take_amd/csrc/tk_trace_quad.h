@@ -242,11 +242,15 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
             const bool occ = group_max_i<G>(my_prim) >= 0;
             if (gl == 0) io.store_occlusion(tag, occ);
         } else {
-            // the lane holding the closest candidate writes it (highest lane on an exact tie)
-            const int win = group_max_i<G>((my_prim >= 0 && my_t == tbest) ? gl : -1);
+            // the lane holding the closest candidate writes it; at exactly equal distances the primitive with the
+            // highest shape id wins (here and in the leaf phase), so the result does not depend on the tree
+            // (shape ids are re-read from the primitive records at these rare points instead of living in a register)
+            const bool mine = my_prim >= 0 && my_t == tbest;
+            const int my_shape = mine ? ((const PrimRec<R> *)prim_base)[my_prim].shape_id : -1;
+            const int win = group_max_i<G>(my_shape);
             if (win < 0) {
                 if (gl == 0) io.store_hit(tag, -1, ray.tmax, R(0), R(0));
-            } else if (gl == win) {
+            } else if (my_shape == win) {
                 io.store_hit(tag, my_prim, my_t, my_u, my_v);
             }
         }
@@ -428,11 +432,14 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                     const uint32_t off = (uint32_t)(first + k) * (uint32_t)sizeof(PrimRec<R>);
                     const PrimRec<R> p = *(const PrimRec<R> *)(prim_base + off);
                     R t, u = R(0), v = R(0);
-                    // later primitives of this lane see the distance of its earlier hits (<= keeps the last on a tie)
+                    // later primitives of this lane see the distance of its earlier hits; the tests accept t == limit,
+                    // and an equal distance replaces the candidate only for a higher shape id (tree-independent ties)
                     const R tlim = tk_fmin(tbest, my_t);
                     const bool ok = ((p.meta & 0xff) == PRIM_TRIANGLE) ? tri_test(p.a, ray, tlim, t, u, v)
                                                                        : sphere_test(p.a, ray, tlim, t);
-                    if (ok) {
+                    bool take = ok;
+                    if (ok && t == my_t) take = p.shape_id > ((const PrimRec<R> *)prim_base)[my_prim].shape_id;  // rare
+                    if (take) {
                         my_t = t, my_u = u, my_v = v;
                         my_prim = first + k;
                     }

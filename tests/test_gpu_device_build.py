@@ -1,0 +1,112 @@
+"""BVH built on the device (TakeBuildOpts.builder = TAKE_BUILDER_DEVICE_LBVH, take_amd/csrc/tk_build_gpu.h) against the
+host SAH build and the oracle.  The tree is different (Morton order, no SAH), the RESULTS must not be: the box tests
+are conservative, so closest hits, occlusion and whole images are required to be bit-identical."""
+import time
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import GOLDEN_SCENES, golden_scene, random_rays, rays_to_abi
+from take_amd import capi, scenes
+from take_amd import cdefs as D
+
+pytestmark = pytest.mark.gpu
+DEV = D.TAKE_BUILDER_DEVICE_LBVH
+
+
+@pytest.mark.parametrize("name", GOLDEN_SCENES)
+def test_device_built_tree_gives_exhaustive_search_hits(name):
+    sd = golden_scene(name)
+    rays = random_rays(20000, 5, tmin=1e-7).astype(np.float32).astype(np.float64)
+    osc = oracle.OracleScene(sd, precision=0)
+    want = osc.isect_brute(rays)
+    osc.close()
+    sc = capi.Scene(sd, precision=D.TAKE_PRECISION_F32, builder=DEV)
+    hits = sc.trace_closest(rays_to_abi(rays, 0))
+    occ = sc.trace_any(rays_to_abi(rays, 0))
+    st = sc.stats()
+    sc.close()
+    assert st["n_prims"] == sd.n_shapes and st["depth"] >= 1
+    assert np.array_equal(hits["shape_id"], want[:, 0].astype(np.int32))
+    hit = want[:, 0] >= 0
+    for k, col in (("t", 1), ("u", 2), ("v", 3)):
+        assert np.array_equal(hits[k][hit].astype(np.float64), want[hit, col]), k
+    assert np.array_equal(occ.astype(bool), hit)
+
+
+@pytest.mark.parametrize("name", ["cbox", "mats", "meshlight"])
+def test_device_and_host_builds_render_the_same_image(name):
+    sd = golden_scene(name)
+    a = capi.Scene(sd, builder=D.TAKE_BUILDER_HOST_SAH)
+    b = capi.Scene(sd, builder=DEV)
+    try:
+        assert np.array_equal(a.render(spp=4, max_depth=50, seed=3), b.render(spp=4, max_depth=50, seed=3))
+    finally:
+        a.close()
+        b.close()
+
+
+@pytest.mark.parametrize("leaf", [1, 2, 4])
+def test_device_build_leaf_sizes_100k(leaf):
+    sd = scenes.soup_scene(100_000, 256, 256, spp=1)
+    a = capi.Scene(sd)
+    b = capi.Scene(sd, builder=DEV, max_leaf_size=leaf)
+    try:
+        rays = rays_to_abi(random_rays(100_000, 11, tmin=1e-4).astype(np.float32).astype(np.float64), 0)
+        ha, hb = a.trace_closest(rays), b.trace_closest(rays)
+        for f in ("shape_id", "t", "u", "v"):
+            assert np.array_equal(ha[f], hb[f]), f
+        assert np.array_equal(a.trace_any(rays), b.trace_any(rays))
+        assert np.array_equal(a.render(spp=2, max_depth=50, seed=1), b.render(spp=2, max_depth=50, seed=1))
+    finally:
+        a.close()
+        b.close()
+
+
+def test_device_build_1m_triangles_same_results_and_build_time():
+    sd = scenes.soup_scene(1_000_000, 1920, 1080, spp=1)
+    t0 = time.time()
+    a = capi.Scene(sd)
+    t_host = time.time() - t0
+    t0 = time.time()
+    b = capi.Scene(sd, builder=DEV)
+    t_dev = time.time() - t0
+    try:
+        sa, sb = a.stats(), b.stats()
+        print(f"\n1M triangles: scene_create host SAH {t_host:.2f} s ({sa['n_nodes']} nodes, depth {sa['depth']}), "
+              f"device LBVH {t_dev:.2f} s ({sb['n_nodes']} nodes, depth {sb['depth']})")
+        assert sb["n_prims"] == sa["n_prims"]
+        rays = rays_to_abi(random_rays(200_000, 3, tmin=1e-4).astype(np.float32).astype(np.float64), 0)
+        ha, hb = a.trace_closest(rays), b.trace_closest(rays)
+        for f in ("shape_id", "t", "u", "v"):
+            assert np.array_equal(ha[f], hb[f]), f
+        assert np.array_equal(a.render(spp=1, max_depth=50, seed=4), b.render(spp=1, max_depth=50, seed=4))
+        for sc, nm in ((a, "host SAH"), (b, "device LBVH")):
+            sc.set_instrumentation(timing=True, counting=True)
+            sc.render(spp=1, max_depth=50, seed=4)
+            c = sc.counters()
+            sc.set_instrumentation(False, False)
+            rays_n = c["rays_closest"] + c["rays_shadow"]
+            print(f"  {nm}: {c['node_visits'] / rays_n:.1f} nodes/ray, {c['prim_tests'] / rays_n:.1f} prims/ray")
+    finally:
+        a.close()
+        b.close()
+
+
+def test_device_build_with_coincident_primitives():
+    """thousands of primitives with the same Morton code (identical triangles): the index tie-break keeps the tree
+    balanced; whatever the builder decides (device tree or host fall-back), results equal the host build's"""
+    sd = scenes.soup_scene(64, 64, 64, spp=1)
+    tri = np.array([[0.1, 0.1, 0.0], [0.3, 0.1, 0.0], [0.2, 0.3, 0.0]])
+    pos = np.tile(tri, (5000, 1))
+    sd.add_mesh(pos, np.arange(15000, dtype=np.int32).reshape(-1, 3), 0)
+    a = capi.Scene(sd)
+    b = capi.Scene(sd, builder=DEV)
+    try:
+        rays = rays_to_abi(random_rays(20000, 9, tmin=1e-4).astype(np.float32).astype(np.float64), 0)
+        ha, hb = a.trace_closest(rays), b.trace_closest(rays)
+        assert np.array_equal(ha["t"], hb["t"]) and np.array_equal(a.trace_any(rays), b.trace_any(rays))
+    finally:
+        a.close()
+        b.close()
