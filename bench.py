@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--spb", type=int, default=0, help="samples per pixel per batch (0 = auto)")
     ap.add_argument("--materials", default="diffuse", choices=["diffuse", "mixed"],
                     help="mixed = round-robin over 7 BSDFs (configs[4]'s divergence stress; not the default workload)")
+    ap.add_argument("--builder", default="host", choices=["host", "device"],
+                    help="device = LBVH built on the GPU (fast build, slower traversal; not the default workload)")
+    ap.add_argument("--max-leaf", type=int, default=0, help="primitives per BVH leaf (0 = builder default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="640x360x1", help="WxHxSPP of the CPU-baseline sample")
     return ap.parse_args()
@@ -57,8 +60,8 @@ def measured_traffic(args):
     (profiles/r01_traffic.json, written by tools/profile.sh -> tools/profile_summary.py; FETCH_SIZE and WRITE_SIZE
     collected in separate passes).  None when the run is not the default configuration the profile was taken on."""
     path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    default = (args.tris, args.width, args.height, args.spp, args.max_depth, args.spb, args.materials) == (
-        1_000_000, 1920, 1080, 256, 50, 0, "diffuse")
+    default = (args.tris, args.width, args.height, args.spp, args.max_depth, args.spb, args.materials, args.builder,
+               args.max_leaf) == (1_000_000, 1920, 1080, 256, 50, 0, "diffuse", "host", 0)
     if not (default and args.gpus == 1 and os.path.exists(path)):
         return None
     with open(path) as f:
@@ -147,7 +150,8 @@ def main():
     spp_total = args.spp * world  # weak scaling: per-GPU samples fixed
     sd = scenes.soup_scene(args.tris, args.width, args.height, spp=spp_total, max_depth=args.max_depth,
                             materials=args.materials)
-    scene = capi.Scene(sd, precision=D.TAKE_PRECISION_F32)
+    scene = capi.Scene(sd, precision=D.TAKE_PRECISION_F32, max_leaf_size=args.max_leaf,
+                       builder=D.TAKE_BUILDER_DEVICE_LBVH if args.builder == "device" else D.TAKE_BUILDER_HOST_SAH)
     t_setup = time.time() - t0
     stats = scene.stats()
     rows = strip_rows(args.height, rank, world)
@@ -209,7 +213,7 @@ def main():
                                    f"{args.width}x{args.height}, {args.spp} spp per GPU ({spp_total} total), max_depth "
                                    f"{args.max_depth}, no Russian roulette, constant background (no env-map IBL upstream)",
                        "parallelism": f"tile-row strips over {world} GPU(s), scene replicated, one gather",
-                       "bvh": {"nodes": stats["n_nodes"], "prims": stats["n_prims"], "depth": stats["depth"],
+                       "bvh": {"builder": args.builder, "nodes": stats["n_nodes"], "prims": stats["n_prims"], "depth": stats["depth"],
                                "scene_bytes": stats["device_bytes"]},
                        "setup_s": t_setup, "rays_per_sample": (acc["rays_closest"] + acc["rays_shadow"]) * world
                        / max(samples, 1),

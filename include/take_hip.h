@@ -151,7 +151,7 @@ typedef struct TakeSceneDesc {
 typedef struct TakeBuildOpts {
     int32_t precision;     /* TAKE_PRECISION_F32 (production) or _F64 (parity mode) */
     int32_t bvh_threads;   /* host threads for the BVH build; <=0: hardware_concurrency */
-    int32_t max_leaf_size; /* primitives per leaf, 1..4; <=0: default                 */
+    int32_t max_leaf_size; /* primitives per leaf, 1..4; <=0: default (2 host, 1 device) */
     int32_t builder;       /* TAKE_BUILDER_HOST_SAH (0, default: best trees) or
                               TAKE_BUILDER_DEVICE_LBVH (f32 scenes: built on the GPU in
                               milliseconds, Morton-order tree; results are identical,

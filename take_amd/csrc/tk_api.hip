@@ -146,7 +146,9 @@ int build_bvh_device(SceneT<float> &sc, int max_leaf, bool compressed_ok, bool c
     using namespace lbvh;
     HostScene<float> &h = sc.host;
     const int n = (int)sc.prims.n;
-    const int leaf_size = std::max(1, std::min(max_leaf > 0 ? max_leaf : 2, MAX_LEAF));
+    // default 1 primitive per leaf: two Morton neighbours need not be close, and a leaf box around both costs more
+    // primitive tests than the extra node (1M soup, 16 spp: 1 / 2 / 4 per leaf = 55.2 / 38.3 / 30.0 Msamples/s)
+    const int leaf_size = std::max(1, std::min(max_leaf > 0 ? max_leaf : 1, MAX_LEAF));
     const int n_leaves = (n + leaf_size - 1) / leaf_size;
     if (n_leaves < 2) return 1;
     hipStream_t stream = nullptr;
