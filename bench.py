@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--spb", type=int, default=0, help="samples per pixel per batch (0 = auto)")
     ap.add_argument("--materials", default="diffuse", choices=["diffuse", "mixed"],
                     help="mixed = round-robin over 7 BSDFs (configs[4]'s divergence stress; not the default workload)")
+    ap.add_argument("--no-envmap", dest="envmap", action="store_false",
+                    help="drop the procedural 2048x1024 sky (configs[2]'s importance-sampled env-map IBL, on by default; "
+                         "an extension — the reference has only a constant background)")
     ap.add_argument("--builder", default="host", choices=["host", "device"],
                     help="device = LBVH built on the GPU (fast build, slower traversal; not the default workload)")
     ap.add_argument("--max-leaf", type=int, default=0, help="primitives per BVH leaf (0 = builder default)")
@@ -61,7 +64,7 @@ def measured_traffic(args):
     collected in separate passes).  None when the run is not the default configuration the profile was taken on."""
     path = os.path.join(ROOT, "profiles", "r01_traffic.json")
     default = (args.tris, args.width, args.height, args.spp, args.max_depth, args.spb, args.materials, args.builder,
-               args.max_leaf) == (1_000_000, 1920, 1080, 256, 50, 0, "diffuse", "host", 0)
+               args.max_leaf, args.envmap) == (1_000_000, 1920, 1080, 256, 50, 0, "diffuse", "host", 0, True)
     if not (default and args.gpus == 1 and os.path.exists(path)):
         return None
     with open(path) as f:
@@ -93,13 +96,16 @@ def cpu_baseline(args, sd_full):
 
     w, h, spp = (int(x) for x in args.cpu_sample.split("x"))
     cores = usable_cpus()
-    sd = scenes.soup_scene(args.tris, w, h, spp=spp, max_depth=args.max_depth, materials=args.materials)
+    sd = scenes.soup_scene(args.tris, w, h, spp=spp, max_depth=args.max_depth, materials=args.materials,
+                           envmap=(2048, 1024) if args.envmap else None)
     samples = w * h * spp
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     sample = f"{args.tris}-tri soup, {w}x{h}, {spp} spp, max_depth {args.max_depth}"
     if os.path.exists(harness):
+        # the reference has no environment-map light: it renders the same scene with its constant background
+        sd_ref = scenes.soup_scene(args.tris, w, h, spp=spp, max_depth=args.max_depth, materials=args.materials)
         with tempfile.TemporaryDirectory() as td:
-            xml = scenes.write_reference_inputs(sd, td)
+            xml = scenes.write_reference_inputs(sd_ref, td)
             r = subprocess.run([harness, "time", xml, str(args.max_depth), str(cores)], stdout=subprocess.PIPE,
                                stderr=subprocess.STDOUT, text=True, timeout=1500)
         secs = None
@@ -108,7 +114,8 @@ def cpu_baseline(args, sd_full):
                 secs = float(line.split("Took")[1].split()[0])
         if r.returncode == 0 and secs:
             return {"value": samples / secs / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "reference",
-                    "sample": sample + " (reference render() timer, seed-patched build)"}
+                    "sample": sample + " (reference render() timer, seed-patched build"
+                              + ("; without the env-map light, which the reference does not have)" if args.envmap else ")")}
     import oracle
 
     osc = oracle.OracleScene(sd, precision=1)
@@ -149,7 +156,7 @@ def main():
     t0 = time.time()
     spp_total = args.spp * world  # weak scaling: per-GPU samples fixed
     sd = scenes.soup_scene(args.tris, args.width, args.height, spp=spp_total, max_depth=args.max_depth,
-                            materials=args.materials)
+                            materials=args.materials, envmap=(2048, 1024) if args.envmap else None)
     scene = capi.Scene(sd, precision=D.TAKE_PRECISION_F32, max_leaf_size=args.max_leaf,
                        builder=D.TAKE_BUILDER_DEVICE_LBVH if args.builder == "device" else D.TAKE_BUILDER_HOST_SAH)
     t_setup = time.time() - t0
@@ -211,7 +218,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"procedural {args.tris}-triangle soup ({args.materials} materials) in 5-wall box + 1 quad area light, "
                                    f"{args.width}x{args.height}, {args.spp} spp per GPU ({spp_total} total), max_depth "
-                                   f"{args.max_depth}, no Russian roulette, constant background (no env-map IBL upstream)",
+                                   f"{args.max_depth}, no Russian roulette, "
+                                   + ("procedural sky env-map 2048x1024, importance-sampled (extension)" if args.envmap
+                                      else "constant background (no env-map IBL upstream)"),
                        "parallelism": f"tile-row strips over {world} GPU(s), scene replicated, one gather",
                        "bvh": {"builder": args.builder, "nodes": stats["n_nodes"], "prims": stats["n_prims"], "depth": stats["depth"],
                                "scene_bytes": stats["device_bytes"]},

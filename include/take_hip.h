@@ -106,8 +106,12 @@ typedef struct TakeSphere {
 /* reference `Light = variant<PointLight, DiffuseAreaLight>` (src/light.h:9-19) */
 typedef struct TakeLight {
     int32_t kind;      /* 0 = PointLight (counts toward N, contributes nothing:
-                          src/integrator/path_tracing.h:33), 1 = DiffuseAreaLight */
-    int32_t shape_id;  /* DiffuseAreaLight::shape_id (index into the shape arrays) */
+                          src/integrator/path_tracing.h:33), 1 = DiffuseAreaLight,
+                          2 = environment map (EXTENSION, not in the reference: equirectangular
+                          image, y up, row 0 = zenith; importance-sampled by luminance*sin(theta),
+                          seen by rays that leave the scene instead of `background`; at most one) */
+    int32_t shape_id;  /* kind 1: DiffuseAreaLight::shape_id (index into the shape arrays);
+                          kind 2: index into `images`; `intensity` then scales the image   */
     double intensity[3];
     double position[3];
 } TakeLight;

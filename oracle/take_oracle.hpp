@@ -215,6 +215,18 @@ template <class R> struct Image3 {  // image.h:13-39
     std::vector<V3<R>> data;
     const V3<R> &at(int x, int y) const { return data[(size_t)y * width + x]; }
 };
+// EXTENSION (not in the reference, which has only a constant background — SURVEY.md §0): an environment-map light,
+// TakeLight kind 2.  Equirectangular image, y up, row 0 = zenith; radiance = nearest texel * scale; sampled with the
+// piecewise-constant density luminance * sin(theta_row).  This is the specification the device code
+// (take_amd/csrc/tk_shade.h: env_*) is held to; parity is against THIS restatement plus analytic tests
+// ("parity unpinned" with respect to the reference).
+template <class R> struct EnvLight {
+    int light = -1;  // index in `lights`, -1 = none
+    int image = -1;
+    V3<R> scale{R(0), R(0), R(0)};
+    std::vector<R> marginal;     // height + 1 row CDF values
+    std::vector<R> conditional;  // height rows of width + 1 column CDF values
+};
 template <class R> struct Scene {
     TakeCamera camera;
     std::vector<Shape<R>> shapes;
@@ -223,6 +235,7 @@ template <class R> struct Scene {
     std::vector<Material<R>> materials;
     std::vector<Image3<R>> images;
     V3<R> background;
+    EnvLight<R> env;
     std::vector<BVHNode<R>> bvh_nodes;
     int bvh_root = -1;
     R ray_eps = K<R>::EPS;  // c_EPSILON in its ray-offset role (render.cpp:75, path_tracing.h:53,79)
@@ -287,6 +300,88 @@ template <class R> void scene_from_desc(const TakeSceneDesc &d, Scene<R> &s) {
         s.images[i].data.resize(n);
         for (size_t k = 0; k < n; k++) s.images[i].data[k] = cv3<R>(d.images[i].data + 3 * k);
     }
+    // environment map: sampling tables from the image as given (double), stored in R
+    s.env = EnvLight<R>{};
+    for (int i = 0; i < d.n_lights; i++) {
+        if (d.lights[i].kind != 2) continue;
+        const TakeImage3 &im = d.images[d.lights[i].shape_id];
+        const int w = im.width, h = im.height;
+        std::vector<double> cond((size_t)h * (w + 1)), marg((size_t)h + 1), rows(h);
+        for (int y = 0; y < h; y++) {
+            const double weight = std::sin(3.14159265358979323846 * (y + 0.5) / h);
+            double acc = 0;
+            for (int x = 0; x < w; x++) {
+                const double *t = im.data + 3 * ((size_t)y * w + x);
+                const double lum = 0.2126 * t[0] + 0.7152 * t[1] + 0.0722 * t[2];
+                cond[(size_t)y * (w + 1) + x] = acc;
+                acc += (lum > 0 ? lum : 0.0) * weight;
+            }
+            rows[y] = acc;
+            for (int x = 0; x < w; x++) {
+                double &c = cond[(size_t)y * (w + 1) + x];
+                c = acc > 0 ? c / acc : (double)x / w;
+            }
+            cond[(size_t)y * (w + 1) + w] = 1.0;
+        }
+        double total = 0;
+        for (int y = 0; y < h; y++) marg[y] = total, total += rows[y];
+        for (int y = 0; y < h; y++) marg[y] /= total;
+        marg[h] = 1.0;
+        s.env.light = i;
+        s.env.image = d.lights[i].shape_id;
+        s.env.scale = cv3<R>(d.lights[i].intensity);
+        s.env.marginal.assign(marg.begin(), marg.end());
+        s.env.conditional.assign(cond.begin(), cond.end());
+    }
+}
+
+// ------------------------------------------------------------------ environment map (extension, see EnvLight)
+template <class R> struct EnvSample {
+    V3<R> dir, radiance;
+    R pdf;
+};
+template <class R> inline V3<R> env_radiance(const Scene<R> &sc, int x, int y) {
+    return sc.images[sc.env.image].at(x, y) * sc.env.scale;
+}
+template <class R> inline R env_density(const Scene<R> &sc, int x, int y, R sin_theta) {
+    if (!(sin_theta > R(0))) return R(0);
+    const int w = sc.images[sc.env.image].width, h = sc.images[sc.env.image].height;
+    const R *row = sc.env.conditional.data() + (size_t)y * (w + 1);
+    const R p = (sc.env.marginal[y + 1] - sc.env.marginal[y]) * (row[x + 1] - row[x]) * R(w) * R(h);
+    return p / (R(2) * K<R>::PI * K<R>::PI * sin_theta);
+}
+template <class R> inline V3<R> env_eval(const Scene<R> &sc, const V3<R> &d, R &pdf) {
+    const int w = sc.images[sc.env.image].width, h = sc.images[sc.env.image].height;
+    const R cy = std::clamp(d.y, R(-1), R(1));
+    const R theta = std::acos(cy);
+    const R u = std::atan2(d.z, d.x) * K<R>::INVTWOPI + R(0.5);
+    const int x = std::clamp((int)std::floor(u * R(w)), 0, w - 1);
+    const int y = std::clamp((int)std::floor(theta * K<R>::INVPI * R(h)), 0, h - 1);
+    pdf = env_density(sc, x, y, std::sqrt(std::fmax(R(0), R(1) - cy * cy)));
+    return env_radiance(sc, x, y);
+}
+template <class R> inline int cdf_interval(const R *cdf, int n, R xi) {  // largest i < n with cdf[i] <= xi
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] <= xi) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+template <class R, class Rng> inline EnvSample<R> env_sample(const Scene<R> &sc, Rng &rng) {
+    const int w = sc.images[sc.env.image].width, h = sc.images[sc.env.image].height;
+    const R u1 = Draw<R, Rng>::real(rng);
+    const R u2 = Draw<R, Rng>::real(rng);
+    const int y = cdf_interval(sc.env.marginal.data(), h, u1);
+    const R *row = sc.env.conditional.data() + (size_t)y * (w + 1);
+    const int x = cdf_interval(row, w, u2);
+    const R m0 = sc.env.marginal[y], m1 = sc.env.marginal[y + 1], c0 = row[x], c1 = row[x + 1];
+    const R dv = m1 > m0 ? (u1 - m0) / (m1 - m0) : R(0.5), du = c1 > c0 ? (u2 - c0) / (c1 - c0) : R(0.5);
+    const R theta = (R(y) + dv) / R(h) * K<R>::PI;
+    const R phi = ((R(x) + du) / R(w) - R(0.5)) * K<R>::TWOPI;
+    const R st = std::sin(theta);
+    return {V3<R>{st * std::cos(phi), std::cos(theta), st * std::sin(phi)}, env_radiance(sc, x, y), env_density(sc, x, y, st)};
 }
 
 // ------------------------------------------------------------------ src/bbox.h:18-55
@@ -754,7 +849,13 @@ template <class R, class Rng>
 V3<R> path_tracing(const Scene<R> &sc, const Ray<R> &ray, Rng &rng, int max_depth, PathCounters *pc = nullptr) {
     Ray<R> r = ray;
     auto v_ = scene_intersect(sc, r, pc ? &pc->closest : nullptr);
-    if (!v_) return sc.background;
+    if (!v_) {
+        if (sc.env.light >= 0) {  // extension: the camera ray sees the environment map
+            R unused;
+            return env_eval(sc, r.dir, unused);
+        }
+        return sc.background;
+    }
     Intersection<R> v = *v_;
     V3<R> radiance{R(0), R(0), R(0)};
     V3<R> throughput{R(1), R(1), R(1)};
@@ -772,7 +873,23 @@ V3<R> path_tracing(const Scene<R> &sc, const Ray<R> &ray, Rng &rng, int max_dept
         if (sc.lights.size() > 0 && !is_specular) {
             int light_id = static_cast<int>(std::floor(Draw<R, Rng>::real(rng) * nlights));  // light.cpp:5-7
             const Light<R> &light = sc.lights[light_id];
-            if (light.kind == 1) {
+            if (light.kind == 2) {
+                // extension: next-event estimation towards the environment map, in the form of the area-light
+                // term below with the map's solid-angle density (over the number of lights) as light_pdf
+                EnvSample<R> es = env_sample(sc, rng);
+                R light_pdf = es.pdf / nlights;
+                if (light_pdf <= 0) break;
+                R bsdf_pdf = get_bsdf_pdf(m, dir_in, es.dir, v, sc);
+                if (bsdf_pdf > 0 && !std::isinf(light_pdf)) {
+                    SampleRecord<R> rec{};
+                    rec.dir_out = es.dir;
+                    V3<R> FG = eval_bsdf(m, dir_in, rec, v, sc);
+                    Ray<R> shadow_r{v.pos, es.dir, sc.ray_eps, K<R>::inf()};
+                    if (!scene_occluded(sc, shadow_r, pc ? &pc->shadow : nullptr)) {
+                        C1 = FG * es.radiance * light_pdf / (light_pdf * light_pdf + bsdf_pdf * bsdf_pdf);
+                    }
+                }
+            } else if (light.kind == 1) {
                 PointAndNormal<R> lp = sample_on_shape(sc, sc.shapes.at(light.shape_id), v.pos, rng);
                 R d = length(lp.position - v.pos);
                 V3<R> light_dir = normalize(lp.position - v.pos);
@@ -805,6 +922,16 @@ V3<R> path_tracing(const Scene<R> &sc, const Ray<R> &ray, Rng &rng, int max_dept
         r = Ray<R>{v.pos, dir_out, sc.ray_eps, K<R>::inf()};
         auto new_v = scene_intersect(sc, r, pc ? &pc->closest : nullptr);
         if (!new_v) {
+            if (sc.env.light >= 0) {
+                // extension: the sampled ray sees the environment map — the emitter-hit term C2 below with the
+                // map's density in the role of light_pdf
+                R env_pdf;
+                V3<R> L = env_eval(sc, dir_out, env_pdf);
+                R lp = env_pdf / nlights;
+                radiance = radiance +
+                           throughput * (FG * L * (is_specular ? (1 / bsdf_pdf) : (bsdf_pdf / (lp * lp + bsdf_pdf * bsdf_pdf))));
+                break;
+            }
             throughput = throughput * (FG / bsdf_pdf);
             radiance = radiance + throughput * sc.background;
             break;

@@ -4,6 +4,7 @@
 // parse_scene and the tile loop (src/render.cpp:37-50) plus build_bvh (src/scene.cpp:4-23).
 #pragma once
 
+#include <cmath>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -29,6 +30,8 @@ template <class R> struct HostScene {
     std::vector<MaterialRec<R>> materials;
     std::vector<ImageInfo> images;
     std::vector<LightRec<R>> lights;
+    EnvMap<R> env{-1, 0, 0, 0, 0, {R(0), R(0), R(0)}, nullptr, nullptr};  // pointers are filled by view() / the uploader
+    std::vector<R> env_marginal, env_conditional;
     R background[3];
     CameraRec<R> cam;
     WideBvhStats stats;
@@ -55,6 +58,9 @@ template <class R> struct HostScene {
         d.images = images.data();
         d.texels = texels.data();
         d.lights = lights.data();
+        d.env = env;
+        d.env.marginal = env_marginal.data();
+        d.env.conditional = env_conditional.data();
         d.n_lights = (int32_t)lights.size();
         d.n_shapes = (int32_t)shapes.size();
         for (int a = 0; a < 3; a++) d.background[a] = background[a];
@@ -85,6 +91,40 @@ template <class R> inline void make_camera(const TakeCamera &c, CameraRec<R> &ou
 }
 
 // returns "" on success, else an error message (-> TAKE_E_INVALID)
+// Sampling tables of an environment map (EnvMap, tk_scene.h), in double: per texel f = luminance * sin(theta of the
+// row centre) with luminance = 0.2126 r + 0.7152 g + 0.0722 b (negatives count as 0); cond[y][x] = sum of the row's
+// f left of x / row sum (x / width for an all-black row), marg[y] = sum of the row sums above y / total.  Both
+// start at 0 and end at exactly 1.  The oracle restates the same recipe (oracle/take_oracle.hpp).
+inline bool env_tables(const double *rgb, int w, int h, std::vector<double> &marg, std::vector<double> &cond) {
+    const double PI_D = 3.14159265358979323846;
+    marg.assign((size_t)h + 1, 0.0);
+    cond.assign((size_t)h * (w + 1), 0.0);
+    std::vector<double> row_sum(h, 0.0);
+    for (int y = 0; y < h; y++) {
+        const double wy = std::sin(PI_D * (y + 0.5) / h);
+        double *c = &cond[(size_t)y * (w + 1)];
+        double run = 0;
+        for (int x = 0; x < w; x++) {
+            const double *t = rgb + 3 * ((size_t)y * w + x);
+            const double lum = 0.2126 * t[0] + 0.7152 * t[1] + 0.0722 * t[2];
+            c[x] = run;
+            run += (lum > 0 ? lum : 0.0) * wy;
+        }
+        row_sum[y] = run;
+        for (int x = 0; x < w; x++) c[x] = run > 0 ? c[x] / run : (double)x / w;
+        c[w] = 1.0;
+    }
+    double total = 0;
+    for (int y = 0; y < h; y++) {
+        marg[y] = total;
+        total += row_sum[y];
+    }
+    if (!(total > 0)) return false;
+    for (int y = 0; y < h; y++) marg[y] /= total;
+    marg[h] = 1.0;
+    return true;
+}
+
 template <class R>
 std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, HostScene<R> &hs, bool build_bvh = true) {
     if (d.camera.width <= 0 || d.camera.height <= 0) return "camera width/height must be positive";
@@ -228,6 +268,8 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
     }
 
     // lights
+    hs.env = EnvMap<R>{-1, 0, 0, 0, 0, {R(0), R(0), R(0)}, nullptr, nullptr};
+    hs.env_marginal.clear(), hs.env_conditional.clear();
     hs.lights.resize(d.n_lights);
     for (int i = 0; i < d.n_lights; i++) {
         const TakeLight &l = d.lights[i];
@@ -237,6 +279,20 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
         o.shape_id = -1;
         for (int a = 0; a < 3; a++) o.intensity[a] = R(l.intensity[a]);
         if (l.kind == 0) continue;
+        if (l.kind == 2) {  // environment map (extension): shape_id = image index, intensity = scale
+            if (hs.env.light >= 0) return "more than one environment-map light";
+            if (l.shape_id < 0 || l.shape_id >= d.n_images) return "environment map: bad image index";
+            const TakeImage3 &im = d.images[l.shape_id];
+            std::vector<double> marg, cond;
+            if (!env_tables(im.data, im.width, im.height, marg, cond)) return "environment map: no positive luminance";
+            hs.env.light = i;
+            hs.env.width = im.width, hs.env.height = im.height;
+            hs.env.texel0 = hs.images[l.shape_id].offset;
+            for (int a = 0; a < 3; a++) hs.env.scale[a] = R(l.intensity[a]);
+            hs.env_marginal.assign(marg.begin(), marg.end());
+            hs.env_conditional.assign(cond.begin(), cond.end());
+            continue;
+        }
         if (l.kind != 1) return "light " + std::to_string(i) + ": unknown kind";
         if (l.shape_id < 0 || l.shape_id >= ns) return "light " + std::to_string(i) + ": bad shape id";
         o.shape_id = l.shape_id;

@@ -102,6 +102,10 @@ TK_HD uint32_t shade_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, c
         // src/integrator/path_tracing.h:7-18
         if (miss) {
             rad = bg;
+            if (sc.env.light >= 0) {  // extension: the camera ray sees the environment map
+                R unused;
+                rad = env_eval(sc, rd, unused);
+            }
         } else if (v.area_light != -1) {
             const LightRec<R> &l = sc.lights[v.area_light];
             if (l.kind == 1) rad = rad + thr * ld3(l.intensity);
@@ -111,7 +115,15 @@ TK_HD uint32_t shade_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, c
         const Vec3<R> FG{st.R_(S_FX, slot), st.R_(S_FY, slot), st.R_(S_FZ, slot)};
         const R pdf = st.R_(S_PDF, slot);
         const bool was_specular = (st.I_(S_FLAGS, slot) & FLAG_SPECULAR) != 0;
-        if (miss) {
+        if (miss && sc.env.light >= 0) {
+            // extension: the BSDF-sampled ray left the scene and sees the environment map — the C2 term of an
+            // emitter hit (path_tracing.h:97-102) with the map's density in the role of light_pdf
+            R env_pdf;
+            const Vec3<R> L = env_eval(sc, rd, env_pdf);
+            const R light_pdf = env_pdf / nlights;
+            rad = rad + thr * (FG * L * (was_specular ? (R(1) / pdf) : (pdf / (light_pdf * light_pdf + pdf * pdf))));
+            thr = thr * (FG / pdf);
+        } else if (miss) {
             thr = thr * (FG / pdf);
             rad = rad + thr * bg;
         } else {
@@ -148,7 +160,29 @@ TK_HD uint32_t shade_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, c
         if (sc.n_lights > 0 && !is_specular) {
             const int light_id = (int)tk_floor(random_real<R>(rng) * nlights);
             const LightRec<R> &l = sc.lights[light_id];
-            if (l.kind == 1) {
+            if (l.kind == 2) {
+                // extension: next-event estimation towards the environment map (same C1 form as an area light,
+                // path_tracing.h:33-58; the shadow ray has no far end)
+                const EnvSample<R> es = env_sample(sc, rng);
+                const R light_pdf = es.pdf / nlights;
+                if (light_pdf <= R(0)) {
+                    alive = false;
+                } else {
+                    const R bp = bsdf_pdf<R, MT>(m, dir_in, es.dir, v);
+                    if (bp > R(0) && !tk_isinf(light_pdf)) {
+                        const Vec3<R> FGl = eval_bsdf<R, MT>(sc, m, dir_in, es.dir, R(0), v);
+                        const Vec3<R> add = thr * (FGl * es.radiance * light_pdf / (light_pdf * light_pdf + bp * bp));
+                        st.R_(S_SX, slot) = es.dir.x;
+                        st.R_(S_SY, slot) = es.dir.y;
+                        st.R_(S_SZ, slot) = es.dir.z;
+                        st.R_(S_ST, slot) = Const<R>::inf();
+                        st.R_(S_CX, slot) = add.x;
+                        st.R_(S_CY, slot) = add.y;
+                        st.R_(S_CZ, slot) = add.z;
+                        req |= REQ_SHADOW;
+                    }
+                }
+            } else if (l.kind == 1) {
                 const LightSample<R> lp = sample_light_point(l, v.pos, rng);
                 const R d = length(lp.pos - v.pos);
                 const Vec3<R> light_dir = normalize(lp.pos - v.pos);

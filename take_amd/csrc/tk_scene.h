@@ -103,8 +103,22 @@ struct ImageInfo {
     int32_t width, height;
     int64_t offset;  // first texel (units: texels) in `texels`
 };
+// Environment-map light (TakeLight kind 2: an EXTENSION — the reference has only a constant background, SURVEY.md
+// §0; BASELINE configs[2] asks for env-map IBL with importance sampling).  Equirectangular image, y up:
+// v = acos(d.y) / pi (row 0 = zenith), u = atan2(d.z, d.x) / 2pi + 1/2; radiance = texel (nearest) * scale, so
+// that the piecewise-constant sampling density below is exact.  marginal: height+1 row CDF values of
+// luminance * sin(theta_row); conditional: per row width+1 column CDF values (both start at 0 and end at 1).
+template <class R> struct EnvMap {
+    int32_t light;   // index of the env light in `lights`, -1 = none (then `background` is used)
+    int32_t width, height;
+    int32_t pad;
+    int64_t texel0;  // first texel of the image in `texels`
+    R scale[3];
+    const R *marginal;
+    const R *conditional;
+};
 template <class R> struct LightRec {
-    int32_t kind;      // 0 point, 1 diffuse area
+    int32_t kind;      // 0 point, 1 diffuse area, 2 environment map (see EnvMap)
     int32_t shape_id;  // -1 for point lights
     int32_t is_sphere;
     int32_t pad;
@@ -140,6 +154,7 @@ template <class R> struct DeviceScene {
     int32_t n_lights;
     int32_t n_shapes;
     R background[3];
+    EnvMap<R> env;
     CameraRec<R> cam;
 };
 

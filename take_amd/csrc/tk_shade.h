@@ -86,6 +86,69 @@ template <class R> TK_HD Vec3<R> eval_texture(const DeviceScene<R> &sc, const Ma
     return (q11 * fx2 * fy2 + q21 * fx1 * fy2 + q12 * fx2 * fy1 + q22 * fx1 * fy1) / R((x2 - x1) * (y2 - y1));
 }
 
+// ---- environment map (extension, see tk_scene.h: EnvMap).  Everything is piecewise constant per texel.
+template <class R> struct EnvSample {
+    Vec3<R> dir;
+    Vec3<R> radiance;
+    R pdf;  // solid-angle density of `dir`
+};
+template <class R> TK_HD Vec3<R> env_texel(const DeviceScene<R> &sc, int x, int y) {
+    const R *t = sc.texels + 3 * (sc.env.texel0 + (int64_t)y * sc.env.width + x);
+    return Vec3<R>{t[0] * sc.env.scale[0], t[1] * sc.env.scale[1], t[2] * sc.env.scale[2]};
+}
+// density of the texel (x, y) over the unit square times the Jacobian of the equirectangular map at polar angle theta
+template <class R> TK_HD R env_texel_pdf(const DeviceScene<R> &sc, int x, int y, R sin_theta) {
+    if (!(sin_theta > R(0))) return R(0);
+    const R *row = sc.env.conditional + (int64_t)y * (sc.env.width + 1);
+    const R p = (sc.env.marginal[y + 1] - sc.env.marginal[y]) * (row[x + 1] - row[x]) * R(sc.env.width) * R(sc.env.height);
+    return p / (R(2) * Const<R>::PI * Const<R>::PI * sin_theta);
+}
+template <class R> TK_HD void env_lookup(const DeviceScene<R> &sc, Vec3<R> d, int &x, int &y, R &sin_theta) {
+    const R cy = tk_clamp(d.y, R(-1), R(1));
+    const R theta = tk_acos(cy);
+    R u = tk_atan2(d.z, d.x) * Const<R>::INVTWOPI + R(0.5);
+    x = (int)tk_floor(u * R(sc.env.width));
+    y = (int)tk_floor(theta * Const<R>::INVPI * R(sc.env.height));
+    x = x < 0 ? 0 : (x >= sc.env.width ? sc.env.width - 1 : x);
+    y = y < 0 ? 0 : (y >= sc.env.height ? sc.env.height - 1 : y);
+    sin_theta = tk_sqrt(tk_fmax(R(0), R(1) - cy * cy));
+}
+// radiance arriving from direction d, and the density with which env_sample would have produced d
+template <class R> TK_HD Vec3<R> env_eval(const DeviceScene<R> &sc, Vec3<R> d, R &pdf) {
+    int x, y;
+    R st;
+    env_lookup(sc, d, x, y, st);
+    pdf = env_texel_pdf(sc, x, y, st);
+    return env_texel(sc, x, y);
+}
+// largest i in [0, n) with cdf[i] <= xi (cdf[0] = 0, cdf[n] = 1, non-decreasing)
+template <class R> TK_HD int cdf_find(const R *cdf, int n, R xi) {
+    int lo = 0, hi = n;  // invariant: cdf[lo] <= xi, and (hi == n or cdf[hi] > xi)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] <= xi) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+template <class R, class G> TK_HD EnvSample<R> env_sample(const DeviceScene<R> &sc, G &rng) {
+    const R u1 = random_real<R>(rng);
+    const R u2 = random_real<R>(rng);
+    const int y = cdf_find(sc.env.marginal, sc.env.height, u1);
+    const R *row = sc.env.conditional + (int64_t)y * (sc.env.width + 1);
+    const int x = cdf_find(row, sc.env.width, u2);
+    const R m0 = sc.env.marginal[y], m1 = sc.env.marginal[y + 1], c0 = row[x], c1 = row[x + 1];
+    const R dv = m1 > m0 ? (u1 - m0) / (m1 - m0) : R(0.5), du = c1 > c0 ? (u2 - c0) / (c1 - c0) : R(0.5);
+    const R theta = (R(y) + dv) / R(sc.env.height) * Const<R>::PI;
+    const R phi = ((R(x) + du) / R(sc.env.width) - R(0.5)) * Const<R>::TWOPI;
+    const R st = tk_sin(theta);
+    EnvSample<R> s;
+    s.dir = Vec3<R>{st * tk_cos(phi), tk_cos(theta), st * tk_sin(phi)};
+    s.radiance = env_texel(sc, x, y);
+    s.pdf = env_texel_pdf(sc, x, y, st);
+    return s;
+}
+
 // ---- materials
 template <class R> struct BsdfSample {
     Vec3<R> dir_out;

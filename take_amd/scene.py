@@ -110,6 +110,16 @@ class SceneData:
         self.shape_area_light = np.concatenate([self.shape_area_light, np.full(1, al, np.int32)])
         return sid
 
+    def add_envmap(self, image, scale=(1.0, 1.0, 1.0)):
+        """Environment-map light (EXTENSION, TakeLight kind 2 — the reference has only `background`): an
+        equirectangular (h, w, 3) radiance image, y up, row 0 = zenith; importance-sampled by luminance * sin(theta)
+        and seen by rays that leave the scene.  It counts as one more light in the uniform light pick."""
+        a = np.ascontiguousarray(image, np.float64)
+        assert a.ndim == 3 and a.shape[2] == 3
+        self.images.append(a)
+        self.lights.append(Light(2, len(self.images) - 1, tuple(float(x) for x in scale)))
+        return len(self.lights) - 1
+
     def add_material(self, tag, color=(0.5, 0.5, 0.5), param=(0.0, 0.0, 0.0, 0.0), tex_image=None,
                      uvxf=(1.0, 1.0, 0.0, 0.0)):
         p = tuple(param) + (0.0,) * (4 - len(param))

@@ -53,9 +53,28 @@ def soup_triangles(n, seed=1234, half=0.9, jitter=0.02):
     return v.reshape(-1, 3), np.arange(3 * n, dtype=np.int32).reshape(n, 3)
 
 
-def soup_scene(n_tris, width, height, spp, seed=1234, jitter=None, max_depth=50, materials="diffuse"):
-    """BASELINE configs[1] (100k) / [2] (1M, constant background): soup + box + quad light, camera (0,0,3.9),
-    fov 39 deg on the x axis, background 0."""
+def sky_envmap(width=2048, height=1024, sun_dir=(0.35, 0.45, 0.82), sun_radiance=400.0, sun_halfangle_deg=3.0):
+    """Procedural equirectangular environment map (configs[2]: "procedural sky + sun"): y up, row 0 = zenith,
+    u = atan2(z, x) / 2pi + 1/2.  Blue-to-white sky gradient above the horizon, dim ground below, one small sun."""
+    v = (np.arange(height) + 0.5) / height
+    u = (np.arange(width) + 0.5) / width
+    theta = v[:, None] * np.pi
+    phi = (u[None, :] - 0.5) * 2.0 * np.pi
+    d = np.stack([np.sin(theta) * np.cos(phi), np.cos(theta) * np.ones_like(phi), np.sin(theta) * np.sin(phi)], -1)
+    up = np.clip(d[..., 1], 0.0, 1.0)
+    sky = (1.0 - up)[..., None] * np.array([1.0, 1.0, 1.0]) + up[..., None] * np.array([0.3, 0.5, 1.0])
+    img = np.where(d[..., 1:2] >= 0.0, 0.8 * sky, np.array([0.08, 0.07, 0.06]))
+    s = np.asarray(sun_dir, np.float64)
+    s = s / np.linalg.norm(s)
+    img = img + (d @ s >= np.cos(np.radians(sun_halfangle_deg)))[..., None] * sun_radiance * np.array([1.0, 0.9, 0.7])
+    return np.ascontiguousarray(img, np.float64)
+
+
+def soup_scene(n_tris, width, height, spp, seed=1234, jitter=None, max_depth=50, materials="diffuse", envmap=None):
+    """BASELINE configs[1] (100k) / [2] (1M): soup + box + quad light, camera (0,0,3.9), fov 39 deg on the x axis,
+    background 0.  envmap = (w, h): adds the procedural sky of sky_envmap as an importance-sampled environment light
+    (configs[2]'s "env-map IBL" — an extension, the reference has no such light); it shines in through the open
+    front of the box."""
     if jitter is None:
         jitter = 0.02 if n_tris <= 200_000 else 0.008
     sd = SceneData(width=width, height=height, lookfrom=(0.0, 0.0, 3.9), lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0),
@@ -81,6 +100,8 @@ def soup_scene(n_tris, width, height, spp, seed=1234, jitter=None, max_depth=50,
         for j, m in enumerate(mats):
             part = tri[j::k]
             sd.add_mesh(part.reshape(-1, 3), np.arange(3 * len(part), dtype=np.int32).reshape(-1, 3), m)
+    if envmap is not None:
+        sd.add_envmap(sky_envmap(int(envmap[0]), int(envmap[1])))
     return sd
 
 
