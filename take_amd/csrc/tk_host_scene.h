@@ -94,7 +94,7 @@ template <class R> inline void make_camera(const TakeCamera &c, CameraRec<R> &ou
 // Sampling tables of an environment map (EnvMap, tk_scene.h), in double: per texel f = luminance * sin(theta of the
 // row centre) with luminance = 0.2126 r + 0.7152 g + 0.0722 b (negatives count as 0); cond[y][x] = sum of the row's
 // f left of x / row sum (x / width for an all-black row), marg[y] = sum of the row sums above y / total.  Both
-// start at 0 and end at exactly 1.  The oracle restates the same recipe (oracle/take_oracle.hpp).
+// start at 0 and end at exactly 1.  (The CPU checker under tests restates this recipe independently.)
 inline bool env_tables(const double *rgb, int w, int h, std::vector<double> &marg, std::vector<double> &cond) {
     const double PI_D = 3.14159265358979323846;
     marg.assign((size_t)h + 1, 0.0);
