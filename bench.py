@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--no-envmap", dest="envmap", action="store_false",
                     help="drop the procedural 2048x1024 sky (configs[2]'s importance-sampled env-map IBL, on by default; "
                          "an extension — the reference has only a constant background)")
+    ap.add_argument("--instanced", default="", metavar="NxT",
+                    help="configs[4]: N instances of a T-triangle mesh, flattened, mixed BSDFs (e.g. 1000x10000); replaces "
+                         "the soup (not the default workload)")
     ap.add_argument("--builder", default="host", choices=["host", "device"],
                     help="device = LBVH built on the GPU (fast build, slower traversal; not the default workload)")
     ap.add_argument("--max-leaf", type=int, default=0, help="primitives per BVH leaf (0 = builder default)")
@@ -64,7 +67,7 @@ def measured_traffic(args):
     collected in separate passes).  None when the run is not the default configuration the profile was taken on."""
     path = os.path.join(ROOT, "profiles", "r01_traffic.json")
     default = (args.tris, args.width, args.height, args.spp, args.max_depth, args.spb, args.materials, args.builder,
-               args.max_leaf, args.envmap) == (1_000_000, 1920, 1080, 256, 50, 0, "diffuse", "host", 0, True)
+               args.max_leaf, args.envmap, args.instanced) == (1_000_000, 1920, 1080, 256, 50, 0, "diffuse", "host", 0, True, "")
     if not (default and args.gpus == 1 and os.path.exists(path)):
         return None
     with open(path) as f:
@@ -155,8 +158,14 @@ def main():
 
     t0 = time.time()
     spp_total = args.spp * world  # weak scaling: per-GPU samples fixed
-    sd = scenes.soup_scene(args.tris, args.width, args.height, spp=spp_total, max_depth=args.max_depth,
-                            materials=args.materials, envmap=(2048, 1024) if args.envmap else None)
+    if args.instanced:
+        n_inst, n_tri = (int(x) for x in args.instanced.split("x"))
+        sd = scenes.instanced_scene(n_inst, n_tri, args.width, args.height, spp=spp_total, max_depth=args.max_depth)
+        if args.envmap:
+            sd.add_envmap(scenes.sky_envmap(2048, 1024))
+    else:
+        sd = scenes.soup_scene(args.tris, args.width, args.height, spp=spp_total, max_depth=args.max_depth,
+                               materials=args.materials, envmap=(2048, 1024) if args.envmap else None)
     scene = capi.Scene(sd, precision=D.TAKE_PRECISION_F32, max_leaf_size=args.max_leaf,
                        builder=D.TAKE_BUILDER_DEVICE_LBVH if args.builder == "device" else D.TAKE_BUILDER_HOST_SAH)
     t_setup = time.time() - t0
@@ -216,7 +225,9 @@ def main():
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"procedural {args.tris}-triangle soup ({args.materials} materials) in 5-wall box + 1 quad area light, "
+            "config": {"workload": (f"{args.instanced} instances x triangles (flattened, 7 BSDFs round-robin)" if args.instanced else
+                                    f"procedural {args.tris}-triangle soup ({args.materials} materials)")
+                                   + " in 5-wall box + 1 quad area light, "
                                    f"{args.width}x{args.height}, {args.spp} spp per GPU ({spp_total} total), max_depth "
                                    f"{args.max_depth}, no Russian roulette, "
                                    + ("procedural sky env-map 2048x1024, importance-sampled (extension)" if args.envmap
@@ -234,7 +245,7 @@ def main():
                          "avg_launch_ms": avg_ms, "bytes_per_ray": bytes_per_ray,
                          "rays_per_launch": acc["rays_closest"] / n_launch},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.instanced:
             try:
                 line["cpu_baseline"] = cpu_baseline(args, sd)
             except Exception as e:  # the bench line must still come out
