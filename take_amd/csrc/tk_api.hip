@@ -592,8 +592,8 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
             const int32_t *shade_in = sc.queue[cur].p;
             if (sort_materials) {
                 tm.begin(TK_OTHER);
-                hipLaunchKernelGGL((k_sort_count<R>), dim3(wide_grid), dim3(BLOCK), 0, stream, st, sc.queue[cur].p, n_cur,
-                                   sc.sort_keys.p, sc.sort_hist.p);
+                hipLaunchKernelGGL((k_sort_count<R>), dim3(wide_grid), dim3(BLOCK), 0, stream, sc.dev.prims, st,
+                                   sc.queue[cur].p, n_cur, sc.sort_keys.p, sc.sort_hist.p);
                 hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(SORT_SCAN_THREADS), 0, stream, sc.sort_hist.p,
                                    sc.sort_base.p, tag_count, wide_grid * (BLOCK / WAVE));
                 hipLaunchKernelGGL(k_sort_scatter, dim3(wide_grid), dim3(BLOCK), 0, stream, sc.queue[cur].p, n_cur,

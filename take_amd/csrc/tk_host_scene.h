@@ -210,7 +210,6 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
 
     // shapes -> primitive records (shape order for now) + build boxes
     const int64_t ns = d.n_shapes;
-    if (ns >= MAX_PRIMS) return "too many shapes (the hit word of a path holds 27 bits of primitive index)";
     hs.shapes.resize(ns);
     std::vector<PrimRec<R>> recs(ns);
     std::vector<BuildPrim> bp(ns);

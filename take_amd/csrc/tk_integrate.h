@@ -86,7 +86,7 @@ constexpr int TAG_MISS = 12;   // the segment of the sorted queue holding the pa
 template <class R, int TAG = TAG_ANY>
 TK_HD uint32_t shade_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, const PathState<R> &st, int64_t slot,
                           int k) {
-    const int32_t hit_prim = hit_word_prim(st.I_(S_HIT, slot));
+    const int32_t hit_prim = st.I_(S_HIT, slot);
     const Vec3<R> ro{st.R_(S_OX, slot), st.R_(S_OY, slot), st.R_(S_OZ, slot)};
     const Vec3<R> rd{st.R_(S_DX, slot), st.R_(S_DY, slot), st.R_(S_DZ, slot)};
     Vec3<R> thr{st.R_(S_TX, slot), st.R_(S_TY, slot), st.R_(S_TZ, slot)};

@@ -177,13 +177,7 @@ enum StateR {
     S_NUM_R = 29
 };
 enum StateI { S_HIT = 9, S_CTR = 10, S_FLAGS = 11, S_NUM_I = 3 };  // integer words of the same record
-// S_HIT: -1 = the extend ray missed; else primitive index (27 bits) | material tag of the primitive << 27.  The tag
-// rides along so that the material sort reads one word of the path record instead of chasing prim -> meta.
-constexpr int HIT_PRIM_BITS = 27;
-constexpr int64_t MAX_PRIMS = (int64_t)1 << HIT_PRIM_BITS;
-TK_HD int32_t hit_word(int32_t prim, int32_t meta) { return prim < 0 ? -1 : (prim | (((meta >> 8) & 0xf) << HIT_PRIM_BITS)); }
-TK_HD int32_t hit_word_prim(int32_t w) { return w < 0 ? -1 : (w & ((1 << HIT_PRIM_BITS) - 1)); }
-TK_HD int32_t hit_word_tag(int32_t w) { return (w >> HIT_PRIM_BITS) & 0xf; }  // meaningful when w >= 0
+// S_HIT: index of the hit primitive (leaf order), -1 = the extend ray missed
 constexpr int PATH_REC = 32;
 constexpr int32_t FLAG_SPECULAR = 1;
 

@@ -37,6 +37,9 @@ namespace tk {
 #ifndef TQ_NODE_ITERS_DEF
 #define TQ_NODE_ITERS_DEF 6
 #endif
+#ifndef TQ_TIEBREAK
+#define TQ_TIEBREAK 1  // 0: experiments only — exact ties in t go to the last candidate seen (tree-dependent)
+#endif
 constexpr int TQ_BLOCK = 256;                 // 4 waves = 64 quads
 constexpr int TQ_QUADS = TQ_BLOCK / 4;
 constexpr int TQ_LEVELS = 32;                 // per-quad stack levels in LDS (8 B each: 17 KB per block)
@@ -105,9 +108,10 @@ template <class R> struct PathIo {  // the render loop: rays in the path state, 
             ray = make_ray(st.R_(S_OX, slot), st.R_(S_OY, slot), st.R_(S_OZ, slot), st.R_(S_SX, slot), st.R_(S_SY, slot),
                            st.R_(S_SZ, slot), eps, st.R_(S_ST, slot));
     }
-    // (the primitive's meta is re-read here, once per ray, rather than kept in a register through the traversal)
+    // (no loads here: the end of a ray sits on the critical path of the whole wave — one dependent load in this
+    // function cost the closest-hit kernel 6 %)
     __device__ __forceinline__ void store_hit(int64_t slot, int32_t prim, R t, R u, R v) const {
-        st.I_(S_HIT, slot) = prim >= 0 ? hit_word(prim, prims[prim].meta) : -1;
+        st.I_(S_HIT, slot) = prim;
         st.R_(S_HT, slot) = t;
         st.R_(S_HU, slot) = u;
         st.R_(S_HV, slot) = v;
@@ -190,6 +194,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
     const int grp = threadIdx.x >> GG::LOG2;  // group within the block
     lds_entry *const stk = (lds_entry *)&s_stack[grp];  // this group's column; level l at stk[l * STRIDE]
     tq_entry *const spl = spill.base + ((int64_t)blockIdx.x * GG::GROUPS + grp);
+    auto spill_at = [&](int level) -> tq_entry * { return spl + (int64_t)(level - GG::LEVELS) * spill.stride; };
     const int32_t n = n_ptr ? *n_ptr : n_direct;
     if (blockIdx.x == 0 && threadIdx.x == 0 && counter_word >= 0)
         atomicAdd(&counters[counter_word], (unsigned long long)n);
@@ -221,7 +226,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
         if (level < GG::LEVELS)
             *lds_level(level) = e;
         else
-            tq_spill_store(spl + (int64_t)(level - GG::LEVELS) * spill.stride, e);
+            tq_spill_store(spill_at(level), e);
     };
     // Next subtree that can still hold a closer hit (entries whose entry distance is beyond the closest hit are
     // dropped).  Returns true when the stack is empty: the ray is finished.
@@ -229,7 +234,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
         for (;;) {
             if (sp == 0) return true;
             --sp;
-            const tq_entry e = (sp < GG::LEVELS) ? *lds_level(sp) : tq_spill_load(spl + (int64_t)(sp - GG::LEVELS) * spill.stride);
+            const tq_entry e = (sp < GG::LEVELS) ? *lds_level(sp) : tq_spill_load(spill_at(sp));
             cur = (int32_t)(uint32_t)e;
             if (ANY_HIT) return false;  // the limit of a shadow ray never shrinks: nothing to cull
             const float key = __uint_as_float((uint32_t)(e >> 32) & ~3u);
@@ -242,15 +247,36 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
             const bool occ = group_max_i<G>(my_prim) >= 0;
             if (gl == 0) io.store_occlusion(tag, occ);
         } else {
-            // the lane holding the closest candidate writes it; at exactly equal distances the primitive with the
-            // highest shape id wins (here and in the leaf phase), so the result does not depend on the tree
-            // (shape ids are re-read from the primitive records at these rare points instead of living in a register)
-            const bool mine = my_prim >= 0 && my_t == tbest;
-            const int my_shape = mine ? ((const PrimRec<R> *)prim_base)[my_prim].shape_id : -1;
-            const int win = group_max_i<G>(my_shape);
-            if (win < 0) {
+            // the lane holding the closest candidate writes it.  At exactly equal distances (a ray through an edge
+            // shared by two triangles) the candidate with the larger (u, v) wins, here and in the leaf phase: a rule
+            // on values every tree produces identically, so the image does not depend on the builder — and one that
+            // needs no load (the end of a ray is on the critical path of the wave).
+            bool mine = my_prim >= 0 && my_t == tbest;
+            bool any = mine;
+            if (!TQ_TIEBREAK) {
+                const int win = group_max_i<G>(mine ? gl : -1);
+                any = win >= 0, mine = gl == win;
+            } else if (G >= 2) {
+                const bool pm = dpp_i<QP_X1>((int)mine) != 0;
+                const R pu = dpp_f<QP_X1>(my_u), pv = dpp_f<QP_X1>(my_v);
+                any = any || pm;
+                if (mine && pm && (pu > my_u || (pu == my_u && (pv > my_v || (pv == my_v && (gl & 1) == 0))))) mine = false;
+            }
+            if (TQ_TIEBREAK && G >= 4) {  // winners of the two pairs against each other
+                const bool pm = dpp_i<QP_X2>((int)mine) != 0;
+                const R pu = dpp_f<QP_X2>(my_u), pv = dpp_f<QP_X2>(my_v);
+                const bool pany = dpp_i<QP_X2>((int)any) != 0;
+                // the partner lane (gl ^ 2) need not be its pair's winner: look at both lanes of the other pair
+                const bool qm = dpp_i<QP_X1>(dpp_i<QP_X2>((int)mine)) != 0;
+                const R qu = dpp_f<QP_X1>(dpp_f<QP_X2>(my_u)), qv = dpp_f<QP_X1>(dpp_f<QP_X2>(my_v));
+                const bool lose_p = pm && (pu > my_u || (pu == my_u && (pv > my_v || (pv == my_v && (gl & 2) == 0))));
+                const bool lose_q = qm && (qu > my_u || (qu == my_u && (qv > my_v || (qv == my_v && (gl & 2) == 0))));
+                if (mine && (lose_p || lose_q)) mine = false;
+                any = any || pany;
+            }
+            if (!any) {
                 if (gl == 0) io.store_hit(tag, -1, ray.tmax, R(0), R(0));
-            } else if (my_shape == win) {
+            } else if (mine) {
                 io.store_hit(tag, my_prim, my_t, my_u, my_v);
             }
         }
@@ -422,10 +448,11 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
         }
         // ------------------------------------------------------------------ leaf phase: primitives dealt to the lanes
         {
-            const bool at_leaf = (uint32_t)cur > (uint32_t)CHILD_EMPTY;
+            const int32_t leaf = cur;
+            const bool at_leaf = (uint32_t)leaf > (uint32_t)CHILD_EMPTY;
             if (COUNT && lane == 0 && tq_ballot(at_leaf) != 0) cnt_wleaf++;
             if (at_leaf) {
-                const int first = leaf_first(cur), cnt = leaf_count(cur);
+                const int first = leaf_first(leaf), cnt = leaf_count(leaf);
                 if (COUNT && gl == 0) cnt_prims += (uint32_t)cnt, cnt_leaves++;
 #pragma unroll 1
                 for (int k = gl; k < cnt; k += G) {
@@ -433,12 +460,12 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                     const PrimRec<R> p = *(const PrimRec<R> *)(prim_base + off);
                     R t, u = R(0), v = R(0);
                     // later primitives of this lane see the distance of its earlier hits; the tests accept t == limit,
-                    // and an equal distance replaces the candidate only for a higher shape id (tree-independent ties)
+                    // and an equal distance replaces the candidate only for a larger (u, v) (tree-independent ties)
                     const R tlim = tk_fmin(tbest, my_t);
                     const bool ok = ((p.meta & 0xff) == PRIM_TRIANGLE) ? tri_test(p.a, ray, tlim, t, u, v)
                                                                        : sphere_test(p.a, ray, tlim, t);
                     bool take = ok;
-                    if (ok && t == my_t) take = p.shape_id > ((const PrimRec<R> *)prim_base)[my_prim].shape_id;  // rare
+                    if (TQ_TIEBREAK && ok && t == my_t) take = u > my_u || (u == my_u && v > my_v);  // rare: an exact tie
                     if (take) {
                         my_t = t, my_u = u, my_v = v;
                         my_prim = first + k;

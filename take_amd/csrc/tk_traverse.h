@@ -211,7 +211,7 @@ TK_HD void traverse(const DeviceScene<R> &sc, const RayT<R> &ray, Stack &stack, 
                 R t, u = R(0), v = R(0);
                 bool ok = ((p.meta & 0xff) == PRIM_TRIANGLE) ? tri_test(p.a, ray, tbest, t, u, v)
                                                              : sphere_test(p.a, ray, tbest, t);
-                if (ok && (t < tbest || hit.prim < 0 || p.shape_id > hit.shape)) {  // ties: highest shape id, any tree
+                if (ok && (t < tbest || hit.prim < 0 || u > hit.u || (u == hit.u && v > hit.v))) {  // ties: larger (u, v), any tree
                     tbest = t;
                     hit.shape = p.shape_id;
                     hit.prim = first + k;
