@@ -421,7 +421,7 @@ struct Timer {
 template <class R, class Io>
 void launch_trace(int group, bool any, bool count, dim3 grid, hipStream_t stream, const DeviceScene<R> &dev, const Io &io,
                   const int32_t *n_ptr, int32_t n_direct, int32_t *head, unsigned long long *counters, int counter_word,
-                  QuadSpill spill) {
+                  StackSpill spill) {
 #define TK_LAUNCH_Q(G, A, C, Q)                                                                                         \
     hipLaunchKernelGGL((k_trace_group<R, G, A, C, Io, Q>), grid, dim3(TQ_BLOCK), 0, stream, dev, io, n_ptr, n_direct, head, \
                        counters, counter_word, spill)
@@ -550,7 +550,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     Timer tm{ts, stream, timing};
     int32_t *q = sc.qwords.p;
     int32_t *tag_count = q + Q_NUM_WORDS;
-    QuadSpill spill{sc.spill.p, sc.spill_stride};
+    StackSpill spill{sc.spill.p, sc.spill_stride};
     const PathIo<R> io_ext0{sc.dev.prims, st, sc.queue[0].p, rp.ray_eps}, io_ext1{sc.dev.prims, st, sc.queue[1].p, rp.ray_eps};
     const PathIo<R> io_shadow{sc.dev.prims, st, sc.shadow_queue.p, rp.ray_eps};
     const dim3 tgrid(sc.trace_grid);
@@ -681,7 +681,7 @@ int trace_impl(TakeScene *ts, const void *d_rays, int64_t n, void *d_hits, int32
                hipStream_t stream) {
     SceneT<R> &sc = pick<R>(ts);
     if (n < 0 || n >= ((int64_t)1 << 31) - (1 << 26)) return fail(TAKE_E_INVALID, "ray count out of range");
-    QuadSpill spill{sc.spill.p, sc.spill_stride};
+    StackSpill spill{sc.spill.p, sc.spill_stride};
     int32_t *q = sc.qwords.p;
     HIP_TRY(hipMemsetAsync(q + Q_HEAD_CLOSEST, 0, sizeof(int32_t), stream));
     HIP_TRY(hipMemsetAsync(sc.counters.p, 0, sc.counters.bytes(), stream));

@@ -1,18 +1,21 @@
-// tk_trace_quad.h — quad traversal: 4 lanes cooperate on one ray (a wave carries 16 rays).
+// tk_trace_quad.h — the trace kernel: G lanes cooperate on one ray (G = 2 "pair" is the production setting; G = 4
+// "quad" and G = 1 are kept as instances of the same template for A/B runs and pass the same parity suite).
 //
-// Why (profiles/r01_a_perlane_bvh4_spp4.txt): with one ray per lane every node visit is eight scattered 16-byte
-// requests per lane, 64 different lines per wave instruction, and a wave runs as long as its slowest of 64 rays
-// (VALU lane efficiency ~14 %, 63 % of wave cycles waiting on memory).  Here
-//   * lane j of a quad loads child slot j of the 128-byte node: one wave instruction reads 16 whole cache lines,
-//     4 lanes per line (2 x dwordx4 per lane) — 4x fewer L1 line look-ups per node visit;
-//   * the four child boxes are tested in parallel, ordered by entry distance with quad DPP broadcasts
-//     (no LDS, no sorting network on one lane), pushed far-to-near on a per-quad LDS stack;
-//   * a leaf (<= 4 primitives) is tested in one step, one primitive per lane; the closest distance is a 2-step
-//     quad min; hit attributes stay in the lane that found them until the ray is finished;
-//   * a wave keeps a pool of 64 queue indices (one atomic per 64 rays) and refills idle quads from it, so lanes do
-//     not idle behind the longest ray of the wave.
-// Same conservative box test and the same primitive tests as tk_traverse.h: results are bit-identical to the
-// per-lane traversal (and to the oracle) up to exact ties.
+// Why lanes share a ray (profiles/r01_a_perlane_bvh4_spp4.txt): with one ray per lane every node visit is eight
+// scattered 16-byte requests per lane, 64 different lines per wave instruction, and a wave runs as long as its
+// slowest of 64 rays (VALU lane efficiency ~14 %).  Here
+//   * the lanes of a group split the four child slots of a wide node: one line look-up per ray per load
+//     instruction (the vector L1 charges exactly that, profiles/r01_ubench_gather.txt); with the 64-byte
+//     compressed node (QN) a pair needs 2 x dwordx4 per lane and no cross-lane traffic before the ranking;
+//   * the four entry distances are ranked with DPP exchanges on integer keys (no LDS, no sorting network); the
+//     nearest child stays in a register, the others go far-to-near on a per-group LDS stack (spill area in global
+//     memory behind an out-of-line call);
+//   * a leaf is tested one primitive per lane; hit attributes stay in the lane that found them until the ray ends;
+//   * node steps and leaf steps run in separate phases; a wave keeps a pool of 64 queue indices (one atomic per
+//     64 rays) and refills idle ray slots from it, so lanes do not idle behind the longest ray of the wave;
+//   * nothing that loads sits at the end of a ray: that point is on the critical path of the whole wave.
+// Same conservative box tests and the same primitive tests as tk_traverse.h: results are bit-identical to the
+// per-lane traversal and to the oracle; exact ties in t are resolved on (u, v), not on visiting order.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -40,14 +43,8 @@ namespace tk {
 #ifndef TQ_TIEBREAK
 #define TQ_TIEBREAK 1  // 0: experiments only — exact ties in t go to the last candidate seen (tree-dependent)
 #endif
-constexpr int TQ_BLOCK = 256;                 // 4 waves = 64 quads
-constexpr int TQ_QUADS = TQ_BLOCK / 4;
-constexpr int TQ_LEVELS = 32;                 // per-quad stack levels in LDS (8 B each: 17 KB per block)
-constexpr int TQ_STRIDE = TQ_QUADS + 4;       // level stride in entries: 544 B = 32 (mod 128) -> conflict-free quads
-constexpr int TQ_SPILL = 68;                  // deeper levels in global memory (per quad); builder caps depth at 96
-constexpr int TQ_NODE_ITERS = TQ_NODE_ITERS_DEF;             // at most this many node steps before the next leaf phase / refill check
-constexpr int TQ_NODE_MIN_QUADS = 6;          // leave the node phase when fewer quads than this are at interior nodes
-constexpr int TQ_REFILL_MIN = 4;              // refill when at least this many of the 16 quads are idle
+constexpr int TQ_BLOCK = 256;                     // 4 waves
+constexpr int TQ_NODE_ITERS = TQ_NODE_ITERS_DEF;  // at most this many node steps before the next leaf phase / refill check
 constexpr uint32_t TQ_KEY_INVALID = 0x7FFFFFFFu;  // above every finite non-negative float's bit pattern, below 2^31
 
 typedef unsigned long long tq_entry;          // low word: child word, high word: order key (float bits | lane)
@@ -57,7 +54,7 @@ __device__ __forceinline__ uint64_t tq_ballot(bool p) { return __builtin_amdgcn_
 // 1 if a < b for keys below 2^31 (no carry/SGPR traffic: one subtract, one shift)
 __device__ __forceinline__ int tq_less(uint32_t a, uint32_t b) { return (int)((a - b) >> 31); }
 
-// ---- quad cross-lane helpers (DPP quad_perm: no LDS traffic)
+// ---- cross-lane helpers inside a group (DPP quad_perm: no LDS traffic)
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v) {
     return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
 }
@@ -72,18 +69,9 @@ constexpr int QP_B0 = 0x00, QP_B1 = 0x55, QP_B2 = 0xAA, QP_B3 = 0xFF;  // broadc
 constexpr int QP_X1 = 0xB1;                                            // [1,0,3,2]
 constexpr int QP_EVEN = 0xA0, QP_ODD = 0xF5;                           // [0,0,2,2] / [1,1,3,3]: one lane of each pair
 constexpr int QP_X2 = 0x4E;                                            // [2,3,0,1]
-template <class R> __device__ __forceinline__ R quad_min(R v) {
-    v = tk_fmin(v, dpp_f<QP_X1>(v));
-    return tk_fmin(v, dpp_f<QP_X2>(v));
-}
-__device__ __forceinline__ int quad_max_i(int v) {
-    v = max(v, dpp_i<QP_X1>(v));
-    return max(v, dpp_i<QP_X2>(v));
-}
-
-struct QuadSpill {
-    tq_entry *base;  // [level][global quad]
-    int64_t stride;  // quads in the persistent grid
+struct StackSpill {
+    tq_entry *base;  // [level][ray group of the persistent grid]
+    int64_t stride;  // ray groups in the persistent grid
 };
 // The overflow path of the stack is kept out of line so that the common path compiles to plain ds_write_b64 /
 // ds_read_b64 (a pointer select between LDS and global memory turns every access into a flat_* instruction).
@@ -167,7 +155,7 @@ template <int G> struct GroupGeom {
     static constexpr int PER_WAVE = 64 / G;
     static constexpr int LEVELS = G == 4 ? 32 : (G == 2 ? TQ_PAIR_LEVELS : 16);  // stack levels in LDS
     static constexpr int STRIDE = GROUPS + 4;            // entries per level (+4: 32 B skew between levels)
-    static constexpr int SPILL = 100 - LEVELS;           // deeper levels in global memory; builder caps depth at 96
+    static constexpr int SPILL = MAX_STACK_ENTRIES + 4 - LEVELS;  // deeper levels in global memory (the builders cap the depth)
 };
 template <int G, class T> __device__ __forceinline__ T group_min(T v) {
     if (G >= 2) v = tk_fmin(v, dpp_f<QP_X1>(v));
@@ -182,9 +170,9 @@ template <int G> __device__ __forceinline__ int group_max_i(int v) {
 
 // QN: traverse the 64-byte compressed nodes (sc.qnodes; f32 pairs only) instead of the 128-byte ones.
 template <class R, int G, bool ANY_HIT, bool COUNT, class Io, bool QN = false>
-__global__ void __launch_bounds__(TQ_BLOCK, TQ_MIN_WAVES)
+__global__ void __launch_bounds__(TQ_BLOCK, sizeof(R) == 8 ? 4 : TQ_MIN_WAVES)  // f64 (parity mode): room for the wider state
 k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_t n_direct, int32_t *head,
-              unsigned long long *counters, int counter_word, QuadSpill spill) {
+              unsigned long long *counters, int counter_word, StackSpill spill) {
     using GG = GroupGeom<G>;
     constexpr int CPL = GG::CPL;
     __shared__ tq_entry s_stack[GG::LEVELS * GG::STRIDE];
