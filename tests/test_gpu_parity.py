@@ -271,3 +271,26 @@ def test_empty_and_tiny_inputs():
     want = osc.render(2, 2, rng_mode=oracle.RNG_COUNTER, seed=1)
     osc.close()
     assert rmse(got, want) < 1e-9
+
+
+def test_scene_lifecycle_releases_device_memory():
+    """create / render / destroy, both builders, several times: HBM in use returns to where it started"""
+    import torch
+
+    sd = scenes.soup_scene(200_000, 256, 256, spp=1, envmap=(256, 128))
+
+    def cycle(i):
+        sc = capi.Scene(sd, builder=D.TAKE_BUILDER_DEVICE_LBVH if i % 2 else D.TAKE_BUILDER_HOST_SAH)
+        sc.render(spp=2, max_depth=8, seed=i)
+        sc.trace_closest(rays_to_abi(random_rays(1000, i), 0))
+        sc.close()
+
+    for i in range(2):
+        cycle(i)  # first use of each path loads code objects and runtime pools once
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for i in range(6):
+        cycle(i)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free0 - free1) < 16 << 20, (free0, free1)  # six more scenes: nothing accumulates
