@@ -110,3 +110,47 @@ def test_device_build_with_coincident_primitives():
     finally:
         a.close()
         b.close()
+
+
+def test_device_builder_request_on_tiny_and_f64_scenes_uses_the_host_builder():
+    """fewer than 8 shapes, or a double-precision scene: the request is honoured by the host builder (documented
+    fall-back), results as usual"""
+    from take_amd.scene import SceneData
+
+    sd = SceneData(width=16, height=16, lookfrom=(0.0, 0.0, 3.0), lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), vfov=40.0,
+                   background=(0.2, 0.3, 0.4), spp=1, max_depth=3)
+    m = sd.add_material(D.MAT_DIFFUSE, (0.5, 0.5, 0.5))
+    pos, idx, nrm, uv = scenes._quad((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1))
+    sd.add_mesh(pos, idx, m, normals=nrm, uvs=uv)
+    a = capi.Scene(sd)
+    b = capi.Scene(sd, builder=DEV)
+    assert np.array_equal(a.render(spp=2, max_depth=3, seed=1), b.render(spp=2, max_depth=3, seed=1))
+    a.close(), b.close()
+    big = golden_scene("soup1k")
+    a = capi.Scene(big, precision=D.TAKE_PRECISION_F64)
+    b = capi.Scene(big, precision=D.TAKE_PRECISION_F64, builder=DEV)
+    assert np.array_equal(a.render(spp=1, max_depth=5, seed=1), b.render(spp=1, max_depth=5, seed=1))
+    a.close(), b.close()
+
+
+def test_device_build_wide_node_format():
+    """TAKE_HIP_NODES=wide with the device builder: full-width nodes straight from the collapse kernel"""
+    import os
+
+    sd = scenes.soup_scene(50_000, 128, 128, spp=1)
+    a = capi.Scene(sd, builder=DEV)
+    os.environ["TAKE_HIP_NODES"] = "wide"
+    try:
+        b = capi.Scene(sd, builder=DEV)
+    finally:
+        del os.environ["TAKE_HIP_NODES"]
+    try:
+        for sc, nb in ((a, 64), (b, 128)):
+            sc.set_instrumentation(timing=False, counting=True)
+            img = sc.render(spp=1, max_depth=10, seed=2)
+            assert sc.counters()["node_bytes"] == nb
+            sc.set_instrumentation(False, False)
+        assert np.array_equal(a.render(spp=1, max_depth=10, seed=2), b.render(spp=1, max_depth=10, seed=2))
+    finally:
+        a.close()
+        b.close()
