@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "take_hip.h"
@@ -91,6 +92,21 @@ template <class R> inline void make_camera(const TakeCamera &c, CameraRec<R> &ou
 }
 
 // returns "" on success, else an error message (-> TAKE_E_INVALID)
+// Run fn(begin, end) -> error string on `threads` contiguous chunks of [0, n); returns the error of the lowest chunk
+// that failed ("" if none).  The per-shape loops below are independent per index.
+template <class F> inline std::string for_chunks(int64_t n, int threads, F fn) {
+    threads = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n / 65536 + 1));
+    if (threads == 1) return fn((int64_t)0, n);
+    std::vector<std::string> err(threads);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++)
+        pool.emplace_back([&, t] { err[t] = fn(n * t / threads, n * (t + 1) / threads); });
+    for (auto &th : pool) th.join();
+    for (auto &e : err)
+        if (!e.empty()) return e;
+    return "";
+}
+
 // Sampling tables of an environment map (EnvMap, tk_scene.h), in double: per texel f = luminance * sin(theta of the
 // row centre) with luminance = 0.2126 r + 0.7152 g + 0.0722 b (negatives count as 0); cond[y][x] = sum of the row's
 // f left of x / row sum (x / width for an all-black row), marg[y] = sum of the row sums above y / total.  Both
@@ -213,7 +229,8 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
     hs.shapes.resize(ns);
     std::vector<PrimRec<R>> recs(ns);
     std::vector<BuildPrim> bp(ns);
-    for (int64_t i = 0; i < ns; i++) {
+    std::string shape_err = for_chunks(ns, threads, [&](int64_t i_begin, int64_t i_end) -> std::string {
+    for (int64_t i = i_begin; i < i_end; i++) {
         PrimRec<R> &p = recs[i];
         p = PrimRec<R>{};
         p.shape_id = (int32_t)i;
@@ -265,6 +282,9 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
         p.meta |= hs.materials[material].tag << 8;
         bp[i].id = (int32_t)i;
     }
+    return "";
+    });
+    if (!shape_err.empty()) return shape_err;
 
     // lights
     hs.env = EnvMap<R>{-1, 0, 0, 0, 0, {R(0), R(0), R(0)}, nullptr, nullptr};
@@ -345,7 +365,8 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
     }
     hs.prims.resize(order.size());
     hs.prim_shade.resize(order.size());
-    for (size_t k = 0; k < order.size(); k++) {
+    for_chunks((int64_t)order.size(), threads, [&](int64_t k_begin, int64_t k_end) -> std::string {
+    for (int64_t k = k_begin; k < k_end; k++) {
         hs.prims[k] = recs[bp[order[k]].id];
         const ShapeInfo &si = hs.shapes[hs.prims[k].shape_id];
         PrimShade ps{si.material, si.area_light, -1, si.mesh};
@@ -358,6 +379,8 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
         }
         hs.prim_shade[k] = ps;
     }
+    return "";
+    });
     if (3 * hs.stats.depth + 1 > MAX_STACK_ENTRIES) return "BVH too deep for the traversal stack";
     return "";
 }
