@@ -345,9 +345,26 @@ def make_scene_goldens(names, man):
             man[f"pt-{name}-d{dd}"] = table(f"pt-{name}-d{dd}", np.hstack([o, d, seed]), xml, dd)
 
 
+def make_egress():
+    """tests/golden/egress/: float images and the EXR files the reference's imwrite (tinyexr, half, ZIP) makes of them"""
+    d = os.path.join(GOLD, "egress")
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(99)
+    for name, (w, h) in (("zip_40x37", (40, 37)), ("none_12x9", (12, 9))):
+        img = rng.uniform(0.0, 4.0, (h, w, 3)) ** 3
+        img[0, 0] = (0.0, 1e-9, 65504.0)      # zero, a half denormal after rounding, the largest half
+        img[0, 1] = (1e5, 6.1e-5, 1.00048828125)  # overflow -> inf, smallest normal region, a rounding tie (1 + 2^-11)
+        img[1, 0] = (0.1, 1.0 / 3.0, 2049.0)   # 2049 is a tie between 2048 and 2050
+        np.concatenate([[w, h], img.reshape(-1)]).astype("<f8").tofile(os.path.join(d, name + ".f64"))
+        run("imwrite", os.path.join(d, name + ".f64"), os.path.join(d, name + ".exr"))
+
+
 def main():
     if not os.path.exists(HARNESS):
         raise SystemExit("oracle/_ref/ref_harness missing: run `make -C oracle ref` (needs /root/reference)")
+    if sys.argv[1:] == ["egress"]:
+        make_egress()
+        return
     man = {}
     names = make_scene_files()
     make_tables(man)

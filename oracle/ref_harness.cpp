@@ -119,6 +119,14 @@ int main(int argc, char **argv) {
         write_f64(argv[5], o);
         return 0;
     }
+    if (cmd == "imwrite") {
+        // imwrite <in.f64: w h then w*h*3 doubles, Image3 order> <out.exr|.pfm>   the reference's own writer
+        auto in = read_f64(argv[2]);
+        Image3 img((int)in[0], (int)in[1]);
+        for (size_t i = 0; i < img.data.size(); i++) img.data[i] = Vector3{in[2 + 3 * i], in[3 + 3 * i], in[4 + 3 * i]};
+        imwrite(argv[3], img);
+        return 0;
+    }
     if (cmd == "flatten") {
         // flatten <scene.xml> <out.tkscene>
         Scene scene = parse_scene(std::string(argv[2]));

@@ -42,6 +42,18 @@ def render(params, seed=0, precision=D.TAKE_PRECISION_F32, ray_epsilon=0.0):
         scene.close()
 
 
+def imwrite(path, img):
+    """the reference's imwrite (src/image.cpp:135-177): `.exr` (half, as tinyexr writes it — take_amd/exr.py) or `.pfm`"""
+    if str(path).endswith(".exr"):
+        from .exr import write_exr
+
+        write_exr(path, img)
+    elif str(path).endswith(".pfm"):
+        imwrite_pfm(path, img)
+    else:
+        raise ValueError(f"Unsupported image format: {path}")
+
+
 def imwrite_pfm(path, img):
     """PFM as the reference writes it (src/image.cpp:145-153): header `PF\\nW H\\n-1\\n`, float32 RGB rows in
     Image3 order."""
@@ -49,3 +61,22 @@ def imwrite_pfm(path, img):
     with open(path, "wb") as f:
         f.write(b"PF\n%d %d\n-1\n" % (a.shape[1], a.shape[0]))
         f.write(a.tobytes())
+
+
+def main(argv=None):
+    """`python -m take_amd.render scene.tkscene [-max_depth D]` — the reference's main.cpp:9-27: render, then
+    imwrite("image.exr") into the current directory."""
+    import sys
+
+    params = list(sys.argv[1:] if argv is None else argv)
+    if "-t" in params:  # main.cpp:13-15: thread count of the CPU pool; meaningless here, accepted and dropped
+        i = params.index("-t")
+        del params[i:i + 2]
+    img = render(params)
+    if img.size:
+        imwrite("image.exr", img)
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

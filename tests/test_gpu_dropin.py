@@ -49,6 +49,15 @@ def test_reference_cli_with_gpu_render_matches_c_abi(name, tmp_path):
     want = sc.render(spp=sd.spp, max_depth=5, seed=7)
     sc.close()
     assert got.shape == want.shape and np.array_equal(got, want)
+    # egress: the EXR the reference's own writer left behind == the one the Python mirror writes for the same image
+    from take_amd.exr import read_exr, write_exr
+
+    write_exr(str(tmp_path / "mirror.exr"), want)
+    ref_ch, ref_hdr = read_exr(str(exr))
+    our_ch, our_hdr = read_exr(str(tmp_path / "mirror.exr"))
+    for c in ("B", "G", "R"):
+        assert np.array_equal(ref_ch[c].view(np.uint16), our_ch[c].view(np.uint16)), c
+    assert ref_hdr["channels"] == our_hdr["channels"] and ref_hdr["compression"] == our_hdr["compression"]
 
 
 def test_reference_cli_without_gpu_fails_like_the_parser_does():
