@@ -83,7 +83,6 @@ template <class R> struct SceneT {
     DevBuf<Node4<R>> nodes;
     DevBuf<QNode4> qnodes;
     DevBuf<PrimRec<R>> prims;
-    DevBuf<PrimShade> prim_shade;
     DevBuf<ShapeInfo> shapes;
     DevBuf<MeshInfo> meshes;
     DevBuf<int32_t> face_idx;
@@ -109,11 +108,11 @@ template <class R> struct SceneT {
     int64_t spill_stride = 0;  // ray groups in the persistent trace grid
 
     size_t scene_bytes() const {
-        return nodes.bytes() + qnodes.bytes() + prims.bytes() + prim_shade.bytes() + shapes.bytes() + meshes.bytes() + face_idx.bytes() + normals.bytes() +
+        return nodes.bytes() + qnodes.bytes() + prims.bytes() + shapes.bytes() + meshes.bytes() + face_idx.bytes() + normals.bytes() +
                uvs.bytes() + texels.bytes() + materials.bytes() + images.bytes() + lights.bytes();
     }
     void release() {
-        nodes.release(), qnodes.release(), prims.release(), prim_shade.release(), shapes.release(), meshes.release(), face_idx.release();
+        nodes.release(), qnodes.release(), prims.release(), shapes.release(), meshes.release(), face_idx.release();
         normals.release(), uvs.release(), texels.release(), materials.release(), images.release(), lights.release();
         env_marginal.release(), env_conditional.release();
         state_r.release(), queue[0].release(), queue[1].release(), shadow_queue.release();
@@ -141,7 +140,7 @@ template <class R> SceneT<R> &pick(TakeScene *s);
 template <> SceneT<float> &pick<float>(TakeScene *s) { return s->f; }
 template <> SceneT<double> &pick<double>(TakeScene *s) { return s->d; }
 
-// BVH build on the device (tk_build_gpu.h).  In: sc.prims / sc.prim_shade uploaded in SHAPE order.  Out: both in
+// BVH build on the device (tk_build_gpu.h).  In: sc.prims uploaded in SHAPE order.  Out: the records in
 // leaf order, sc.nodes or sc.qnodes, host-side stats and grid.  Returns TAKE_OK, an error, or 1 = "use the host
 // builder" (tree deeper than the traversal stack allows: long runs of equal Morton codes).
 int build_bvh_device(SceneT<float> &sc, int max_leaf, bool compressed_ok, bool compressed_forced) {
@@ -249,14 +248,11 @@ int build_bvh_device(SceneT<float> &sc, int max_leaf, bool compressed_ok, bool c
     }
     // records into leaf order
     DevBuf<PrimRec<float>> prims_sorted;
-    DevBuf<PrimShade> shade_sorted;
     HIP_TRY(prims_sorted.alloc(n));
-    HIP_TRY(shade_sorted.alloc(n));
     hipLaunchKernelGGL((k_permute<PrimRec<float>>), grid(n), blk, 0, stream, sc.prims.p, vals_s.p, n, prims_sorted.p);
-    hipLaunchKernelGGL((k_permute<PrimShade>), grid(n), blk, 0, stream, sc.prim_shade.p, vals_s.p, n, shade_sorted.p);
     HIP_TRY(hipStreamSynchronize(stream));
-    sc.prims.release(), sc.prim_shade.release();
-    sc.prims = prims_sorted, sc.prim_shade = shade_sorted;  // DevBuf is a plain handle: ownership moves
+    sc.prims.release();
+    sc.prims = prims_sorted;  // DevBuf is a plain handle: ownership moves
     HIP_TRY(hipGetLastError());
     return TAKE_OK;
 }
@@ -282,7 +278,6 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     if (!err.empty()) return fail(TAKE_E_INVALID, err);
     HostScene<R> &h = sc.host;
     HIP_TRY(sc.prims.upload(h.prims));
-    HIP_TRY(sc.prim_shade.upload(h.prim_shade));
     bool use_q = false;
     if (on_device) {
         const int rc = build_bvh_device_any<R>(sc, max_leaf, sc.group == 2 && fmt != "wide", fmt == "q16");
@@ -291,8 +286,7 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
             err = prepare_scene<R>(desc, max_leaf, threads, sc.host, true);
             if (!err.empty()) return fail(TAKE_E_INVALID, err);
             HIP_TRY(sc.prims.upload(h.prims));
-            HIP_TRY(sc.prim_shade.upload(h.prim_shade));
-        } else if (rc != TAKE_OK) {
+                } else if (rc != TAKE_OK) {
             return rc;
         } else {
             use_q = sc.qnodes.p != nullptr;
@@ -321,7 +315,6 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     d.nodes = sc.nodes.p;
     d.qnodes = use_q ? sc.qnodes.p : nullptr;
     d.prims = sc.prims.p;
-    d.prim_shade = sc.prim_shade.p;
     d.shapes = sc.shapes.p;
     d.meshes = sc.meshes.p;
     d.face_idx = sc.face_idx.p;
@@ -510,7 +503,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     const int64_t npix = (int64_t)n_rows * W;
     ts->counters = TakeCounters{};
     ts->counters.node_bytes = sc.dev.qnodes ? sizeof(QNode4) : sizeof(Node4<R>);
-    ts->counters.prim_bytes = sizeof(PrimRec<R>);
+    ts->counters.prim_bytes = PRIM_TEST_BYTES * (int)(sizeof(R) / 4);
     if (npix == 0) return TAKE_OK;
     if (npix >= ((int64_t)1 << 30)) return fail(TAKE_E_INVALID, "image too large");
 
@@ -699,7 +692,7 @@ int trace_impl(TakeScene *ts, const void *d_rays, int64_t n, void *d_hits, int32
     HIP_TRY(hipMemcpy(c, sc.counters.p, sizeof c, hipMemcpyDeviceToHost));
     ts->counters = TakeCounters{};
     ts->counters.node_bytes = sc.dev.qnodes ? sizeof(QNode4) : sizeof(Node4<R>);
-    ts->counters.prim_bytes = sizeof(PrimRec<R>);
+    ts->counters.prim_bytes = PRIM_TEST_BYTES * (int)(sizeof(R) / 4);
     (any ? ts->counters.rays_shadow : ts->counters.rays_closest) = (uint64_t)n;
     ts->counters.node_visits = c[C_NODE_VISITS];
     ts->counters.prim_tests = c[C_PRIM_TESTS];

@@ -22,7 +22,6 @@ template <class R> struct HostScene {
     float grid_lo[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1};
     double q_inflation = 1.0;    // mean surface-area inflation of the compressed child boxes (1 = none)
     std::vector<PrimRec<R>> prims;
-    std::vector<PrimShade> prim_shade;
     int32_t root_child = CHILD_EMPTY;
     std::vector<ShapeInfo> shapes;
     std::vector<MeshInfo> meshes;
@@ -47,7 +46,6 @@ template <class R> struct HostScene {
         d.qnodes = qnodes.empty() ? nullptr : qnodes.data();
         for (int a = 0; a < 3; a++) d.grid_lo[a] = grid_lo[a], d.grid_step[a] = grid_step[a];
         d.prims = prims.data();
-        d.prim_shade = prim_shade.data();
         d.root_child = root_child;
         d.n_nodes = (int32_t)nodes.size();
         d.shapes = shapes.data();
@@ -364,20 +362,19 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
         }
     }
     hs.prims.resize(order.size());
-    hs.prim_shade.resize(order.size());
     for_chunks((int64_t)order.size(), threads, [&](int64_t k_begin, int64_t k_end) -> std::string {
     for (int64_t k = k_begin; k < k_end; k++) {
         hs.prims[k] = recs[bp[order[k]].id];
         const ShapeInfo &si = hs.shapes[hs.prims[k].shape_id];
-        PrimShade ps{si.material, si.area_light, -1, si.mesh};
+        PrimRec<R> &pr = hs.prims[k];
+        pr.material = si.material, pr.area_light = si.area_light, pr.nidx = -1, pr.mesh = si.mesh;
         if (si.mesh >= 0) {
             const MeshInfo &mi = hs.meshes[si.mesh];
             if (mi.nbase >= 0 || mi.uvbase >= 0) {
-                ps.nidx = mi.fbase + si.face;
-                hs.prims[k].meta |= META_HAS_ATTR;
+                pr.nidx = mi.fbase + si.face;
+                pr.meta |= META_HAS_ATTR;
             }
         }
-        hs.prim_shade[k] = ps;
     }
     return "";
     });

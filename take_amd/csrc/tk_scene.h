@@ -60,25 +60,24 @@ constexpr int32_t PRIM_TRIANGLE = 0;
 constexpr int32_t PRIM_SPHERE = 1;
 // triangle: a = v0.xyz, e1.xyz, e2.xyz (e = v_k - v0 in R arithmetic, as the reference computes per test,
 // src/shape.cpp:52-53); sphere: a[0..2] = centre, a[3] = radius.  meta = kind | material tag << 8.
+// The last four words are the shading side of the primitive — what the shade kernel needs right after a hit, without
+// the prim -> shape -> mesh chain of dependent loads — in the same 64-byte record (f32), so a hit costs the shade
+// kernel one line for geometry and shading data together; the trace kernels read only the first 44 bytes.
 template <class R> struct alignas(16) PrimRec {
     R a[9];
     int32_t shape_id;
     int32_t meta;
-    int32_t pad[sizeof(R) == 4 ? 1 : 2];
-};
-static_assert(sizeof(PrimRec<float>) == 48, "48-byte f32 primitive record");
-static_assert(sizeof(PrimRec<double>) == 96 || sizeof(PrimRec<double>) == 88 || sizeof(PrimRec<double>) == 80,
-              "f64 primitive record");
-
-// Shading-side record of a primitive, in leaf order like PrimRec (same index): what the shade kernel needs right
-// after a hit, without the prim -> shape -> mesh chain of dependent loads.
-struct PrimShade {
     int32_t material;
     int32_t area_light;
-    int32_t nidx;   // first of the face's 3 entries in face_idx (units: faces), or -1 when the mesh has neither
-                    // vertex normals nor uvs (then nothing else is read)
-    int32_t mesh;   // mesh id (valid when nidx >= 0)
+    int32_t nidx;  // first of the face's 3 entries in face_idx (units: faces), or -1 when the mesh has neither vertex
+                   // normals nor uvs (then nothing else is read)
+    int32_t mesh;  // mesh id (valid when nidx >= 0)
+    int32_t pad[sizeof(R) == 4 ? 1 : 0];
 };
+static_assert(sizeof(PrimRec<float>) == 64, "64-byte f32 primitive record: two per cache line, never straddling");
+static_assert(sizeof(PrimRec<double>) == 96, "f64 primitive record");
+constexpr int PRIM_TEST_BYTES = 48;  // what a primitive test reads of a record (3 x 16 B): the algorithmic bytes per test
+
 constexpr int32_t META_HAS_ATTR = 1 << 16;  // PrimRec::meta flag: vertex normals and/or uvs exist
 
 struct ShapeInfo {  // indexed by shape id
@@ -139,7 +138,6 @@ template <class R> struct DeviceScene {
     const QNode4 *qnodes;  // f32 only: compressed copy of nodes (same indices); nullptr = traverse the full-width nodes
     float grid_lo[3], grid_step[3];  // the quantisation grid of qnodes
     const PrimRec<R> *prims;
-    const PrimShade *prim_shade;  // same order as prims
     int32_t root_child;  // child word of the root (a leaf word when the scene has <= MAX_LEAF shapes)
     int32_t n_nodes;
     const ShapeInfo *shapes;

@@ -27,9 +27,8 @@ template <class R> TK_HD Vec3<R> ld3(const R *p) { return {p[0], p[1], p[2]}; }
 template <class R>
 TK_HD void make_isect(const DeviceScene<R> &sc, Vec3<R> ro, Vec3<R> rd, int32_t prim, R t, R u, R v, Isect<R> &out) {
     const PrimRec<R> &p = sc.prims[prim];
-    const PrimShade ps = sc.prim_shade[prim];  // independent of the PrimRec load: both are indexed by `prim`
-    out.material = ps.material;
-    out.area_light = ps.area_light;
+    out.material = p.material;
+    out.area_light = p.area_light;
     out.pos = ro + rd * t;
     if ((p.meta & 0xff) == PRIM_SPHERE) {
         Vec3<R> n = normalize(out.pos - Vec3<R>{p.a[0], p.a[1], p.a[2]});
@@ -47,9 +46,9 @@ TK_HD void make_isect(const DeviceScene<R> &sc, Vec3<R> ro, Vec3<R> rd, int32_t 
     out.gn = gn;
     out.uv = {u, v};
     out.sn = gn;
-    if (ps.nidx < 0) return;  // mesh without vertex normals and uvs (src/shape.cpp:90,101)
-    const MeshInfo mi = sc.meshes[ps.mesh];
-    const int32_t *idx = sc.face_idx + 3 * (int64_t)ps.nidx;
+    if (p.nidx < 0) return;  // mesh without vertex normals and uvs (src/shape.cpp:90,101)
+    const MeshInfo mi = sc.meshes[p.mesh];
+    const int32_t *idx = sc.face_idx + 3 * (int64_t)p.nidx;
     const int32_t i0 = idx[0], i1 = idx[1], i2 = idx[2];
     if (mi.uvbase >= 0) {
         const R *uv = sc.uvs + 2 * (int64_t)mi.uvbase;
