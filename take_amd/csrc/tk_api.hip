@@ -91,6 +91,7 @@ template <class R> struct SceneT {
     DevBuf<ImageInfo> images;
     DevBuf<LightRec<R>> lights;
     DevBuf<R> env_marginal, env_conditional;
+    DevBuf<int32_t> env_guide_m, env_guide_c;
     DeviceScene<R> dev{};
     // render workspace (grown on demand)
     DevBuf<R> state_r;
@@ -114,7 +115,7 @@ template <class R> struct SceneT {
     void release() {
         nodes.release(), qnodes.release(), prims.release(), shapes.release(), meshes.release(), face_idx.release();
         normals.release(), uvs.release(), texels.release(), materials.release(), images.release(), lights.release();
-        env_marginal.release(), env_conditional.release();
+        env_marginal.release(), env_conditional.release(), env_guide_m.release(), env_guide_c.release();
         state_r.release(), queue[0].release(), queue[1].release(), shadow_queue.release();
         sorted_queue.release(), sort_keys.release(), sort_hist.release(), sort_base.release(), accum.release(), out.release(), qwords.release(), counters.release(), spill.release();
     }
@@ -309,6 +310,8 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     HIP_TRY(sc.lights.upload(h.lights));
     HIP_TRY(sc.env_marginal.upload(h.env_marginal));
     HIP_TRY(sc.env_conditional.upload(h.env_conditional));
+    HIP_TRY(sc.env_guide_m.upload(h.env_guide_m));
+    HIP_TRY(sc.env_guide_c.upload(h.env_guide_c));
     DeviceScene<R> &d = sc.dev;
     d = h.view();
     d.n_nodes = (int32_t)h.stats.n_nodes;
@@ -326,6 +329,8 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     d.lights = sc.lights.p;
     d.env.marginal = sc.env_marginal.p;
     d.env.conditional = sc.env_conditional.p;
+    d.env.guide_m = sc.env_guide_m.p;
+    d.env.guide_c = sc.env_guide_c.p;
     HIP_TRY(sc.qwords.alloc(Q_NUM_WORDS + 2 * N_SORT_KEYS));
     HIP_TRY(hipMemset(sc.qwords.p, 0, sc.qwords.bytes()));
     HIP_TRY(sc.counters.alloc(C_NUM_WORDS));

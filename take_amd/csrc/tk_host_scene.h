@@ -30,8 +30,9 @@ template <class R> struct HostScene {
     std::vector<MaterialRec<R>> materials;
     std::vector<ImageInfo> images;
     std::vector<LightRec<R>> lights;
-    EnvMap<R> env{-1, 0, 0, 0, 0, {R(0), R(0), R(0)}, nullptr, nullptr};  // pointers are filled by view() / the uploader
+    EnvMap<R> env{-1, 0, 0, 0, 0, {R(0), R(0), R(0)}, nullptr, nullptr, nullptr, nullptr};  // pointers: view() / the uploader
     std::vector<R> env_marginal, env_conditional;
+    std::vector<int32_t> env_guide_m, env_guide_c;
     R background[3];
     CameraRec<R> cam;
     WideBvhStats stats;
@@ -60,6 +61,8 @@ template <class R> struct HostScene {
         d.env = env;
         d.env.marginal = env_marginal.data();
         d.env.conditional = env_conditional.data();
+        d.env.guide_m = env_guide_m.data();
+        d.env.guide_c = env_guide_c.data();
         d.n_lights = (int32_t)lights.size();
         d.n_shapes = (int32_t)shapes.size();
         for (int a = 0; a < 3; a++) d.background[a] = background[a];
@@ -285,8 +288,8 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
     if (!shape_err.empty()) return shape_err;
 
     // lights
-    hs.env = EnvMap<R>{-1, 0, 0, 0, 0, {R(0), R(0), R(0)}, nullptr, nullptr};
-    hs.env_marginal.clear(), hs.env_conditional.clear();
+    hs.env = EnvMap<R>{-1, 0, 0, 0, 0, {R(0), R(0), R(0)}, nullptr, nullptr, nullptr, nullptr};
+    hs.env_marginal.clear(), hs.env_conditional.clear(), hs.env_guide_m.clear(), hs.env_guide_c.clear();
     hs.lights.resize(d.n_lights);
     for (int i = 0; i < d.n_lights; i++) {
         const TakeLight &l = d.lights[i];
@@ -308,6 +311,25 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
             for (int a = 0; a < 3; a++) hs.env.scale[a] = R(l.intensity[a]);
             hs.env_marginal.assign(marg.begin(), marg.end());
             hs.env_conditional.assign(cond.begin(), cond.end());
+            // guide tables over the R-typed CDFs (what the device searches): interval of k / G for k = 0..G
+            auto guide = [](const R *cdf, int n, int g, int32_t *out) {
+                for (int k = 0; k <= g; k++) {
+                    const R xi = R(k) / R(g);
+                    int lo = 0, hi = n;
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (cdf[mid] <= xi) lo = mid;
+                        else hi = mid;
+                    }
+                    out[k] = lo;
+                }
+            };
+            hs.env_guide_m.resize(ENV_GUIDE_M + 1);
+            guide(hs.env_marginal.data(), im.height, ENV_GUIDE_M, hs.env_guide_m.data());
+            hs.env_guide_c.resize((size_t)im.height * (ENV_GUIDE_C + 1));
+            for (int y = 0; y < im.height; y++)
+                guide(hs.env_conditional.data() + (size_t)y * (im.width + 1), im.width, ENV_GUIDE_C,
+                      hs.env_guide_c.data() + (size_t)y * (ENV_GUIDE_C + 1));
             continue;
         }
         if (l.kind != 1) return "light " + std::to_string(i) + ": unknown kind";

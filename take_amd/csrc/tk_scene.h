@@ -115,7 +115,12 @@ template <class R> struct EnvMap {
     R scale[3];
     const R *marginal;
     const R *conditional;
+    // guide tables: entry k of a guide = the CDF interval that holds k / ENV_GUIDE_*; a look-up starts its bisection
+    // between two neighbouring entries (2-3 steps instead of 10-11), with the same result
+    const int32_t *guide_m;  // ENV_GUIDE_M + 1 entries
+    const int32_t *guide_c;  // height rows of ENV_GUIDE_C + 1 entries
 };
+constexpr int ENV_GUIDE_M = 256, ENV_GUIDE_C = 64;
 template <class R> struct LightRec {
     int32_t kind;      // 0 point, 1 diffuse area, 2 environment map (see EnvMap)
     int32_t shape_id;  // -1 for point lights
