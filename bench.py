@@ -12,7 +12,7 @@ estimator).  The background is the reference's constant `background_color`: env-
 scene, the path state and the framebuffer are resident in HBM.
 
 Scaling is weak: every GPU renders 1920x1080x256 samples' worth of work — with N GPUs the image keeps its size, the
-rows are sharded in 16-row strips over the ranks and the sample count per pixel is 256*N.
+rows are sharded in 4-row strips over the ranks and the sample count per pixel is 256*N.
 
 One JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel
 (closest-hit traversal, measured with HIP events inside the timed region) and `cpu_baseline` (rank 0, N = 1 only).

@@ -175,7 +175,7 @@ typedef struct TakeRenderOpts {
                               src/render.cpp:75, path_tracing.h:53,79); <=0: default
                               (1e-7 in f64 as the reference, 1e-4 in f32 — the
                               reference's own commented alternative, src/take.h:31)    */
-    int32_t strip_first;   /* multi-GPU: this rank renders the 16-row strips s with    */
+    int32_t strip_first;   /* multi-GPU: this rank renders the 4-row strips s with     */
     int32_t strip_stride;  /*   s % strip_stride == strip_first (1-GPU: 0 and 1)       */
     int32_t samples_per_batch; /* samples per pixel in flight at once; <=0: auto       */
     int32_t reserved;

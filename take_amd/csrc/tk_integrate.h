@@ -28,7 +28,10 @@ template <class R> struct RenderParams {
     R ray_eps;
 };
 
-constexpr int TILE_ROWS = 16;  // the reference's tile_size (src/render.cpp:52): strips are whole tile rows
+// Multi-GPU unit: a strip of STRIP_ROWS image rows, dealt round-robin to the ranks.  (The reference's own unit is
+// a 16-row tile row, src/render.cpp:52; 4-row strips balance better: 1080 rows over 8 ranks = 136 vs 132 rows per
+// rank instead of 144 vs 128.  Pixel keys do not depend on the sharding, so the image does not either.)
+constexpr int TILE_ROWS = 4;
 
 // local row -> render-loop y (y = 0 is the bottom image row: the reference stores img(x, height - y - 1))
 template <class R> TK_HD int local_row_to_y(const RenderParams<R> &rp, int lr) {

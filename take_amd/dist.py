@@ -1,7 +1,7 @@
 """Multi-GPU sharding of the render: one process per GPU, scene replicated, image rows sharded.
 
 The reference's only parallelism is its tile loop (src/render.cpp:59-82, src/parallel.cpp:183-237): tiles write
-disjoint pixels and read a const scene.  Here the unit handed to a GPU is a 16-row strip (one row of the
+disjoint pixels and read a const scene.  Here the unit handed to a GPU is a 4-row strip (a quarter of a row of the
 reference's 16x16 tiles); rank r of N renders the strips s with s % N == r (interleaved for load balance).
 The random stream of a sample depends only on (seed, pixel, sample), so the image is identical for every N.
 There is no data-path collective: the only exchange is ONE gather of the finished strips to rank 0
@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-TILE_ROWS = 16
+TILE_ROWS = 4  # rows per strip (take_amd/csrc/tk_integrate.h: TILE_ROWS)
 
 
 def strip_rows(height, first, stride):

@@ -42,8 +42,10 @@ def render_opts(spp, max_depth, seed=0, ray_epsilon=0.0, strip_first=0, strip_st
 
 
 def n_local_rows(height, first, stride):
-    n_strips = (height + 15) // 16
-    return sum(min(height, (s + 1) * 16) - s * 16 for s in range(first, n_strips, stride))
+    from take_amd.dist import TILE_ROWS as T
+
+    n_strips = (height + T - 1) // T
+    return sum(min(height, (s + 1) * T) - s * T for s in range(first, n_strips, stride))
 
 
 def hostsim_render(sd, precision, spp, max_depth, seed=0, ray_epsilon=0.0, strip_first=0, strip_stride=1,

@@ -30,7 +30,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        sd = golden_scene("mats")  # 64 x 48 -> 3 strips: ragged over 2 ranks
+        sd = golden_scene("mats")  # 64 x 48 -> 12 strips of 4 rows
         part, _ = hostsim_render(sd, 0, 1, 3, seed=21, strip_first=rank, strip_stride=world)
         assert part.shape[0] == len(strip_rows(sd.height, rank, world))
         full = gather_strips(torch.from_numpy(part), sd.height, rank, world)
@@ -43,7 +43,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 5])  # 12 strips: even over 2 and 3 ranks, ragged (3,3,2,2,2) over 5
 def test_gather_strips_over_gloo(world):
     from helpers import golden_scene, hostsim_render
 
