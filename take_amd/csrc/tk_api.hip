@@ -158,7 +158,8 @@ int build_bvh_device(SceneT<float> &sc, int max_leaf, bool compressed_ok, bool c
     auto grid = [](int64_t items) { return dim3((unsigned)((items + BLK - 1) / BLK)); };
 
     DevBuf<Box> pb, lbox, ibox;
-    DevBuf<uint32_t> keys, vals, keys_s, vals_s, lkey;
+    DevBuf<uint64_t> keys, keys_s, lkey;
+    DevBuf<uint32_t> vals, vals_s;
     DevBuf<int> scene_ord, parent_i, parent_l, flag, frontier[2], lvl;
     DevBuf<int2> child;
     DevBuf<char> temp;
@@ -182,9 +183,9 @@ int build_bvh_device(SceneT<float> &sc, int max_leaf, bool compressed_ok, bool c
     hipLaunchKernelGGL(k_prim_boxes, grid(n), blk, 0, stream, sc.prims.p, n, pb.p, scene_ord.p);
     hipLaunchKernelGGL(k_morton, grid(n), blk, 0, stream, pb.p, n, scene_ord.p, keys.p, vals.p);
     size_t temp_bytes = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n, 0, 30, stream));
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n, 0, 63, stream));
     HIP_TRY(temp.alloc(temp_bytes));
-    HIP_TRY(rocprim::radix_sort_pairs(temp.p, temp_bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n, 0, 30, stream));
+    HIP_TRY(rocprim::radix_sort_pairs(temp.p, temp_bytes, keys.p, keys_s.p, vals.p, vals_s.p, (size_t)n, 0, 63, stream));
 
     HIP_TRY(lbox.alloc(n_leaves));
     HIP_TRY(lkey.alloc(n_leaves));

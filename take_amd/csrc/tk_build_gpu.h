@@ -3,7 +3,8 @@
 //
 //   k_prim_boxes     primitive AABBs (of the geometry the intersection tests see: v0, v0+e1, v0+e2 — one ulp wider)
 //                    + scene bounds (wave reduce, ordered-int atomics)
-//   k_morton         30-bit Morton code of the box centre; rocPRIM radix sort of (code, primitive) pairs
+//   k_morton         63-bit Morton code of the box centre (21 bits per axis: 30 bits leave whole clusters of a 10M-
+//                    triangle scene in one cell); rocPRIM radix sort of (code, primitive) pairs
 //   k_leaves         leaves = runs of `leaf_size` consecutive primitives in Morton order
 //   k_hierarchy      Karras 2012: every internal node finds its key range and split in parallel
 //   k_refit          bottom-up boxes, second arrival at a node computes it (agent-scope fences around the flag)
@@ -100,31 +101,33 @@ __global__ void __launch_bounds__(BLK) k_prim_boxes(const PrimRec<float> *__rest
     }
 }
 
-__device__ __forceinline__ uint32_t expand10(uint32_t v) {  // 10 bits -> every third bit
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
+__device__ __forceinline__ uint64_t expand21(uint64_t v) {  // 21 bits -> every third bit
+    v &= 0x1FFFFFull;
+    v = (v | (v << 32)) & 0x001F00000000FFFFull;
+    v = (v | (v << 16)) & 0x001F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
     return v;
 }
-__global__ void __launch_bounds__(BLK) k_morton(const Box *__restrict__ pb, int n, const int *__restrict__ scene_ord, uint32_t *keys, uint32_t *vals) {
+__global__ void __launch_bounds__(BLK) k_morton(const Box *__restrict__ pb, int n, const int *__restrict__ scene_ord, uint64_t *keys, uint32_t *vals) {
     const int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= n) return;
     const Box b = pb[i];
-    uint32_t q[3];
+    uint64_t q[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float lo = ord2f(scene_ord[k]), hi = ord2f(scene_ord[3 + k]);
         const float ext = hi - lo;
         const float t = ext > 0.0f ? (0.5f * (b.lo[k] + b.hi[k]) - lo) / ext : 0.0f;
-        q[k] = (uint32_t)fminf(fmaxf(t * 1024.0f, 0.0f), 1023.0f);
+        q[k] = (uint64_t)fminf(fmaxf(t * 2097152.0f, 0.0f), 2097151.0f);
     }
-    keys[i] = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+    keys[i] = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
     vals[i] = (uint32_t)i;
 }
 
-__global__ void __launch_bounds__(BLK) k_leaves(const Box *__restrict__ pb, const uint32_t *__restrict__ keys_sorted, const uint32_t *__restrict__ vals_sorted,
-                                                 int n, int leaf_size, int n_leaves, Box *lbox, uint32_t *lkey) {
+__global__ void __launch_bounds__(BLK) k_leaves(const Box *__restrict__ pb, const uint64_t *__restrict__ keys_sorted, const uint32_t *__restrict__ vals_sorted,
+                                                 int n, int leaf_size, int n_leaves, Box *lbox, uint64_t *lkey) {
     const int l = blockIdx.x * BLK + threadIdx.x;
     if (l >= n_leaves) return;
     const int first = l * leaf_size, cnt = min(leaf_size, n - first);
@@ -135,13 +138,13 @@ __global__ void __launch_bounds__(BLK) k_leaves(const Box *__restrict__ pb, cons
 }
 
 // common-prefix length of leaf keys i and j (ties broken by the leaf index), -1 outside the array
-__device__ __forceinline__ int prefix_len(const uint32_t *__restrict__ k, int n, int i, int j) {
+__device__ __forceinline__ int prefix_len(const uint64_t *__restrict__ k, int n, int i, int j) {
     if (j < 0 || j >= n) return -1;
-    const uint32_t a = k[i], b = k[j];
-    return a == b ? 32 + __clz((uint32_t)(i ^ j)) : __clz(a ^ b);
+    const uint64_t a = k[i], b = k[j];
+    return a == b ? 64 + __clz((uint32_t)(i ^ j)) : __clzll((long long)(a ^ b));
 }
 // child reference: >= 0 internal node, < 0 leaf ~l.  parent_i[0] = -1 (root = internal node 0).
-__global__ void __launch_bounds__(BLK) k_hierarchy(const uint32_t *__restrict__ lkey, int n_leaves, int2 *child, int *parent_i, int *parent_l) {
+__global__ void __launch_bounds__(BLK) k_hierarchy(const uint64_t *__restrict__ lkey, int n_leaves, int2 *child, int *parent_i, int *parent_l) {
     const int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= n_leaves - 1) return;
     const int d = prefix_len(lkey, n_leaves, i, i + 1) - prefix_len(lkey, n_leaves, i, i - 1) >= 0 ? 1 : -1;
