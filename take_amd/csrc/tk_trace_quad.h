@@ -377,13 +377,24 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                     if (nhit != 0) {
                         const int pos0 = gl ? theirs : 0, pos1 = pos0 + v0;
                         int32_t cand = CHILD_EMPTY;  // INT_MIN: below every child word
-                        if (v0) {
-                            if (pos0 == 0) cand = child[0];
-                            else push_entry(sp + pos0 - 1, (tq_entry)(uint32_t)child[0]);
-                        }
-                        if (v1) {
-                            if (pos1 == 0) cand = child[CPL - 1];
-                            else push_entry(sp + pos1 - 1, (tq_entry)(uint32_t)child[CPL - 1]);
+                        if (sp + nhit - 1 <= GG::LEVELS) {  // all of this step's entries land in LDS: no per-entry check
+                            if (v0) {
+                                if (pos0 == 0) cand = child[0];
+                                else *lds_level(sp + pos0 - 1) = (tq_entry)(uint32_t)child[0];
+                            }
+                            if (v1) {
+                                if (pos1 == 0) cand = child[CPL - 1];
+                                else *lds_level(sp + pos1 - 1) = (tq_entry)(uint32_t)child[CPL - 1];
+                            }
+                        } else {
+                            if (v0) {
+                                if (pos0 == 0) cand = child[0];
+                                else push_entry(sp + pos0 - 1, (tq_entry)(uint32_t)child[0]);
+                            }
+                            if (v1) {
+                                if (pos1 == 0) cand = child[CPL - 1];
+                                else push_entry(sp + pos1 - 1, (tq_entry)(uint32_t)child[CPL - 1]);
+                            }
                         }
                         sp += nhit - 1;
                         cur = group_max_i<G>(cand);
@@ -420,11 +431,20 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                         // the nearest child is visited next and never touches the stack; the others are pushed
                         // far-to-near, so the next nearest ends on top
                         int32_t cand = CHILD_EMPTY;  // INT_MIN: below every child word
+                        if (sp + nhit - 1 <= GG::LEVELS) {  // all of this step's entries land in LDS: no per-entry check
 #pragma unroll
-                        for (int j = 0; j < CPL; j++) {
-                            if (rank[j] == 0) cand = child[j];  // rank 0 with nhit != 0 is a hit
-                            if (key[j] != TQ_KEY_INVALID && rank[j] != 0)
-                                push_entry(sp + nhit - 1 - rank[j], ((tq_entry)key[j] << 32) | (tq_entry)(uint32_t)child[j]);
+                            for (int j = 0; j < CPL; j++) {
+                                if (rank[j] == 0) cand = child[j];  // rank 0 with nhit != 0 is a hit
+                                if (key[j] != TQ_KEY_INVALID && rank[j] != 0)
+                                    *lds_level(sp + nhit - 1 - rank[j]) = ((tq_entry)key[j] << 32) | (tq_entry)(uint32_t)child[j];
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < CPL; j++) {
+                                if (rank[j] == 0) cand = child[j];
+                                if (key[j] != TQ_KEY_INVALID && rank[j] != 0)
+                                    push_entry(sp + nhit - 1 - rank[j], ((tq_entry)key[j] << 32) | (tq_entry)(uint32_t)child[j]);
+                            }
                         }
                         sp += nhit - 1;
                         cur = group_max_i<G>(cand);
