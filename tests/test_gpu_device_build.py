@@ -157,3 +157,47 @@ def test_device_build_wide_node_format():
     finally:
         a.close()
         b.close()
+
+
+def test_exact_ties_resolve_the_same_way_in_every_tree():
+    """two coplanar, overlapping quads of different colour (every ray into the overlap has an exact tie in t between
+    triangles of the two quads), axis-aligned boxes sharing planes: the (u, v) rule must give one image for the host
+    tree, the device tree, compressed and full-width nodes"""
+    import os
+
+    from take_amd.scene import SceneData
+
+    sd = SceneData(width=96, height=96, lookfrom=(0.3, 0.4, 3.0), lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), vfov=45.0,
+                   background=(0.1, 0.1, 0.1), spp=4, max_depth=6)
+    red = sd.add_material(D.MAT_DIFFUSE, (0.8, 0.1, 0.1))
+    blue = sd.add_material(D.MAT_DIFFUSE, (0.1, 0.1, 0.8))
+    grey = sd.add_material(D.MAT_DIFFUSE, (0.6, 0.6, 0.6))
+    for c, m in (((-0.3, 0.0, 0.0), red), ((0.3, 0.1, 0.0), blue)):  # coplanar (z = 0), overlapping in the middle
+        pos, idx, nrm, uv = scenes._quad(c, (0.7, 0, 0), (0, 0.7, 0), (0, 0, 1))
+        sd.add_mesh(pos, idx, m, normals=nrm, uvs=uv)
+    rng = np.random.default_rng(5)
+    for k in range(64):  # a grid of boxes standing on the plane y = -1, touching their neighbours
+        x, z = (k % 8) * 0.25 - 1.0, (k // 8) * 0.25 - 1.0
+        h = rng.uniform(0.1, 0.5)
+        lo, hi = np.array([x, -1.0, z]), np.array([x + 0.25, -1.0 + h, z + 0.25])
+        corners = np.array([[lo[0], lo[1], lo[2]], [hi[0], lo[1], lo[2]], [hi[0], hi[1], lo[2]], [lo[0], hi[1], lo[2]],
+                            [lo[0], lo[1], hi[2]], [hi[0], lo[1], hi[2]], [hi[0], hi[1], hi[2]], [lo[0], hi[1], hi[2]]])
+        faces = np.array([[0, 1, 2], [0, 2, 3], [4, 6, 5], [4, 7, 6], [0, 4, 5], [0, 5, 1], [3, 2, 6], [3, 6, 7],
+                          [0, 3, 7], [0, 7, 4], [1, 5, 6], [1, 6, 2]], np.int32)
+        sd.add_mesh(corners, faces, grey)
+    pos, idx, nrm, uv = scenes._quad((0, 1.5, 0), (0.5, 0, 0), (0, 0, 0.5), (0, -1, 0))
+    sd.add_mesh(pos, idx, grey, normals=nrm, uvs=uv, emission=(10.0, 10.0, 10.0))
+    imgs = []
+    for builder, fmt in ((D.TAKE_BUILDER_HOST_SAH, None), (DEV, None), (D.TAKE_BUILDER_HOST_SAH, "wide"), (DEV, "wide")):
+        if fmt:
+            os.environ["TAKE_HIP_NODES"] = fmt
+        try:
+            sc = capi.Scene(sd, builder=builder)
+        finally:
+            os.environ.pop("TAKE_HIP_NODES", None)
+        imgs.append(sc.render(spp=4, max_depth=6, seed=8))
+        sc.close()
+    for im in imgs[1:]:
+        assert np.array_equal(imgs[0], im)
+    overlap = imgs[0][40:56, 44:52]  # pixels looking into the overlap: one of the two colours, not a blend of garbage
+    assert np.isfinite(imgs[0]).all() and overlap.mean() > 0
