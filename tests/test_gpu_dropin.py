@@ -72,3 +72,24 @@ def test_reference_cli_without_gpu_fails_like_the_parser_does():
     r = run_cli(os.path.join(GOLD, "scenes", "cbox.xml"), "/tmp", 5, {})
     assert r.returncode != 0
     assert "fl_exception" in r.stderr and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_python_main_writes_the_same_exr_as_the_reference_binary(tmp_path, monkeypatch):
+    """`python -m take_amd.render scene.tkscene -max_depth 5` = the reference's main(): image.exr in the working
+    directory, pixel for pixel the file the reference's writer produces for the same render"""
+    from take_amd import render as R
+    from take_amd.exr import read_exr
+
+    monkeypatch.chdir(tmp_path)
+    assert R.main([os.path.join(GOLD, "scenes", "cbox.tkscene"), "-t", "8", "-max_depth", "5"]) == 0
+    ours, _ = read_exr(str(tmp_path / "image.exr"))
+    if os.path.exists(CLI):
+        sub = tmp_path / "ref"
+        sub.mkdir()
+        r = run_cli(os.path.join(GOLD, "scenes", "cbox.xml"), str(sub), 5, {"TAKE_HIP_SEED": "0"})
+        assert r.returncode == 0, r.stderr[-2000:]
+        ref, _ = read_exr(str(sub / "image.exr"))
+        for c in ("B", "G", "R"):
+            assert np.array_equal(ours[c].view(np.uint16), ref[c].view(np.uint16)), c
+    assert R.render([]).shape == (0, 0, 3)  # src/render.cpp:10-12
