@@ -591,11 +591,14 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
             const int32_t *shade_in = sc.queue[cur].p;
             if (sort_materials) {
                 tm.begin(TK_OTHER);
-                hipLaunchKernelGGL((k_sort_count<R>), dim3(wide_grid), dim3(BLOCK), 0, stream, sc.dev.prims, st,
+                // every wave of the sort gets >= 512 entries of the (bounded) queue: the one-block scan walks
+                // 13 x waves counters, which must not dominate small rounds (it was 40 % of a 256x256 render)
+                const int sort_grid = (int)std::max<int64_t>(1, std::min<int64_t>(wide_grid, (n_bound + 2047) / 2048));
+                hipLaunchKernelGGL((k_sort_count<R>), dim3(sort_grid), dim3(BLOCK), 0, stream, sc.dev.prims, st,
                                    sc.queue[cur].p, n_cur, sc.sort_keys.p, sc.sort_hist.p);
                 hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(SORT_SCAN_THREADS), 0, stream, sc.sort_hist.p,
-                                   sc.sort_base.p, tag_count, wide_grid * (BLOCK / WAVE));
-                hipLaunchKernelGGL(k_sort_scatter, dim3(wide_grid), dim3(BLOCK), 0, stream, sc.queue[cur].p, n_cur,
+                                   sc.sort_base.p, tag_count, sort_grid * (BLOCK / WAVE));
+                hipLaunchKernelGGL(k_sort_scatter, dim3(sort_grid), dim3(BLOCK), 0, stream, sc.queue[cur].p, n_cur,
                                    sc.sort_keys.p, sc.sort_base.p, sc.sorted_queue.p);
                 tm.end();
                 shade_in = sc.sorted_queue.p;
