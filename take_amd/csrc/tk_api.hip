@@ -552,7 +552,10 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     StackSpill spill{sc.spill.p, sc.spill_stride};
     const PathIo<R> io_ext0{sc.dev.prims, st, sc.queue[0].p, rp.ray_eps}, io_ext1{sc.dev.prims, st, sc.queue[1].p, rp.ray_eps};
     const PathIo<R> io_shadow{sc.dev.prims, st, sc.shadow_queue.p, rp.ray_eps};
-    const dim3 tgrid(sc.trace_grid);
+    // persistent trace grid, cut down when the queue (bounded by n_bound) cannot fill it: one block per 128 rays
+    auto trace_grid_for = [&](int64_t n_rays) {
+        return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(sc.trace_grid, (n_rays + 127) / 128)));
+    };
     const int wide_grid = (int)std::min<int64_t>((slots + BLOCK - 1) / BLOCK, (int64_t)ts->num_cus * 8);
     const int pix_grid = (int)std::min<int64_t>((npix + BLOCK - 1) / BLOCK, (int64_t)ts->num_cus * 8);
 
@@ -584,6 +587,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
             int32_t *n_cur = q + (cur ? Q_N_EXT1 : Q_N_EXT0), *n_next = q + (next ? Q_N_EXT1 : Q_N_EXT0);
             hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, stream, q, next);
             tm.begin(TK_CLOSEST);
+            const dim3 tgrid = trace_grid_for(n_bound);
             launch_trace<R>(sc.group, false, counting, tgrid, stream, sc.dev, cur ? io_ext1 : io_ext0, n_cur, 0,
                             q + Q_HEAD_CLOSEST, sc.counters.p, (int)C_RAYS_CLOSEST, spill);
             tm.end();
