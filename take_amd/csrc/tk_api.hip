@@ -513,10 +513,11 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     if (npix == 0) return TAKE_OK;
     if (npix >= ((int64_t)1 << 30)) return fail(TAKE_E_INVALID, "image too large");
 
-    // paths in flight per batch: 128 Mi (17 GB of f32 path state + 2 GB of queues) — bigger batches keep the persistent
-    // trace grid full for more of each bounce (measured on the 1M-triangle scene: 8/16/32/64 spp per batch =
-    // 53.2/57.7/60.3/61.9 Msamples/s), and a 288 GB device has the room; capped at half of what is free now
-    int64_t target = (int64_t)128 << 20;
+    // paths in flight per batch: up to 512 Mi (69 GB of f32 path state + 9 GB of queues) — bigger batches keep the
+    // persistent trace grid full for more of each bounce (measured on the 1M-triangle scene, spp per batch 8 / 16 / 32 /
+    // 64 / 128 / 256 = 53.2 / 57.7 / 60.3 / 61.9 | 64.5 / 64.9 / 65.5 Msamples/s), and a 288 GB device has the room;
+    // capped at half of what is free now
+    int64_t target = (int64_t)512 << 20;
     {
         size_t free_b = 0, total_b = 0;
         const int64_t per_path = (int64_t)PATH_REC * (int64_t)sizeof(R) + 4 * (int64_t)sizeof(int32_t);
