@@ -4,15 +4,21 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json: "Msamples/s ... 1M-tri"; configs[2]): procedural 1M-triangle soup in the 5-wall box with
-one quad light, 1920x1080, 256 samples per pixel per GPU, max_depth 50, no Russian roulette (the reference's
-estimator).  The background is the reference's constant `background_color`: env-map IBL does not exist upstream
- and is not implemented here.  A "step" is one full render: camera rays -> ... -> framebuffer in HBM
-(-> one RCCL gather of the strips to rank 0 when N > 1).  Scene build/upload happen before the timed region; the
-scene, the path state and the framebuffer are resident in HBM.
+Default workload = BASELINE.json configs[2] ("Msamples/s ... 1M-tri"): procedural 1M-triangle soup in the 5-wall box
+with one quad light AND a procedural 2048x1024 sky as an importance-sampled environment-map light (an extension: the
+reference has only a constant background — `--no-envmap` gives the reference's own feature set), 1920x1080, 256
+samples per pixel per GPU, max_depth 50, no Russian roulette (the reference's estimator).  A "step" is one full
+render: camera rays -> ... -> framebuffer in HBM (-> one RCCL gather of the strips to rank 0 when N > 1).  Scene
+build/upload happen before the timed region; the scene, the path state and the framebuffer are resident in HBM.
 
-Scaling is weak: every GPU renders 1920x1080x256 samples' worth of work — with N GPUs the image keeps its size, the
-rows are sharded in 4-row strips over the ranks and the sample count per pixel is 256*N.
+Scaling: the default is weak — every GPU renders 1920x1080x256 samples' worth of work (with N GPUs the image keeps its
+size, the rows are sharded in 4-row strips over the ranks and the sample count per pixel is 256*N).  `--config 3` is
+BASELINE configs[3]: the same scene at 4096x4096 with 1024 spp TOTAL, rows sharded over the N ranks (strong scaling).
+
+Precision: `value` is measured on the production arithmetic (f32).  The reference computes in double
+(src/take.h:27), so at N = 1 the same workload is also timed on the f64 device path (`reference_precision`, the
+path whose images agree with the pinned oracle at rounding level), and `parity` reports the per-pixel RMSE between the
+f32 and the f64 render of this very workload at matched seeds (4 spp).
 
 One JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel
 (closest-hit traversal, measured with HIP events inside the timed region) and `cpu_baseline` (rank 0, N = 1 only).
@@ -56,22 +62,38 @@ def parse_args():
     ap.add_argument("--builder", default="host", choices=["host", "device"],
                     help="device = LBVH built on the GPU (fast build, slower traversal; not the default workload)")
     ap.add_argument("--max-leaf", type=int, default=0, help="primitives per BVH leaf (0 = builder default)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3],
+                    help="BASELINE.json configs index: 2 = 1920x1080x256 spp per GPU (weak scaling, default); 3 = 4096x4096, "
+                         "1024 spp total, rows sharded over the ranks (strong scaling)")
+    ap.add_argument("--f64-steps", type=int, default=2,
+                    help="timed steps of the same workload on the f64 (reference-precision) device path, N = 1 only; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="640x360x1", help="WxHxSPP of the CPU-baseline sample")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config == 3:
+        args.width, args.height, args.spp = 4096, 4096, 1024
+    return args
 
 
 def measured_traffic(args):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
-    (profiles/r01_traffic.json, written by tools/profile.sh -> tools/profile_summary.py; FETCH_SIZE and WRITE_SIZE
-    collected in separate passes).  None when the run is not the default configuration the profile was taken on."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    """HBM-side bytes per launch of the dominant kernel.  PMC counters cannot be read from inside a run: the figure
+    comes from the committed rocprofv3 passes over THIS command (tools/profile_default.sh -> tools/profile_summary.py
+    -> profiles/rNN_traffic.json; FETCH_SIZE and WRITE_SIZE collected in separate passes, corrected with the factor
+    tools/ubench_gather measures for this access pattern).  Returns (bytes or None, source string): None when the
+    run is not the default configuration the profile was taken on."""
     default = (args.tris, args.width, args.height, args.spp, args.max_depth, args.spb, args.materials, args.builder,
-               args.max_leaf, args.envmap, args.instanced) == (1_000_000, 1920, 1080, 256, 50, 0, "diffuse", "host", 0, True, "")
-    if not (default and args.gpus == 1 and os.path.exists(path)):
-        return None
-    with open(path) as f:
-        return json.load(f).get("hbm_bytes_per_launch")
+               args.max_leaf, args.envmap, args.instanced, args.config) == (
+                   1_000_000, 1920, 1080, 256, 50, 0, "diffuse", "host", 0, True, "", 2)
+    if not (default and args.gpus == 1):
+        return None, "not measured for this configuration (PMC passes exist for the default N = 1 command only)"
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                t = json.load(f)
+            return (t.get("hbm_bytes_per_launch_corrected", t.get("hbm_bytes_per_launch")),
+                    f"profiles/{name}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run")
+    return None, "no committed PMC profile"
 
 
 def usable_cpus():
@@ -129,6 +151,62 @@ def cpu_baseline(args, sd_full):
             "sample": sample + " (oracle <double, mt19937> tile loop)"}
 
 
+def f64_leg(args, sd, img32, stream):
+    """Time args.f64_steps steps of the same workload on the f64 device path (N = 1).  Returns the
+    `reference_precision` object and the `parity` object (f32 vs f64 render of this workload at matched seeds)."""
+    import torch
+
+    from take_amd import capi
+    from take_amd import cdefs as D
+
+    t0 = time.time()
+    scene = capi.Scene(sd, precision=D.TAKE_PRECISION_F64, max_leaf_size=args.max_leaf)
+    t_setup = time.time() - t0
+    out = torch.empty((args.height, args.width, 3), dtype=torch.float64, device="cuda")
+    scene.render_device(out.data_ptr(), 1, args.max_depth, seed=7, stream=stream)  # warms the kernels up
+    scene.set_instrumentation(timing=True, counting=False)
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    acc = {"ms_trace_closest": 0.0, "launches_trace_closest": 0, "rays_closest": 0, "rays_shadow": 0,
+           "ms_trace_shadow": 0.0, "ms_shade": 0.0, "ms_other": 0.0, "ms_total": 0.0}
+    for _ in range(args.f64_steps):
+        scene.render_device(out.data_ptr(), args.spp, args.max_depth, seed=0, samples_per_batch=args.spb, stream=stream)
+        c = scene.counters()
+        for k in acc:
+            acc[k] += c[k]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    assert torch.isfinite(out).all()
+    # the timed f32 and f64 steps rendered the same image (seed 0, same spp): their difference is the parity statistic
+    parity = None
+    if img32 is not None:
+        d = (img32 - out).abs().amax(dim=2)
+        parity = {"f32_vs_f64_rmse": float(((img32 - out) ** 2).mean().sqrt()), "spp": args.spp, "seed": 0,
+                  "pixels_within_1e-3": float((d < 1e-3).double().mean()),
+                  "mean_rel_diff": float(((img32.mean() - out.mean()) / out.mean()).abs()),
+                  "note": "per-pixel RMSE between the images of the timed f32 and f64 steps (same workload, matched "
+                          "counter seeds); the f64 device path agrees with the pinned oracle at rounding level "
+                          "(tests/test_gpu_parity.py); f32 bounds per golden scene: tests/test_gpu_precision.py"}
+    samples = args.width * args.height * args.spp * args.f64_steps
+    # algorithmic bytes per ray in this layout (counting pass, 1 spp, never timed)
+    scene.set_instrumentation(timing=False, counting=True)
+    scene.render_device(out.data_ptr(), 1, args.max_depth, seed=0, stream=stream)
+    cc = scene.counters()
+    rays = cc["rays_closest"] + cc["rays_shadow"]
+    bpr = (cc["node_visits"] * cc["node_bytes"] + cc["prim_tests"] * cc["prim_bytes"]) / max(rays, 1) + 2 * STATE_BYTES_PER_RAY - 4
+    n_launch = max(acc["launches_trace_closest"], 1)
+    avg_ms = acc["ms_trace_closest"] / n_launch
+    achieved = bpr * acc["rays_closest"] / n_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    scene.close()
+    ref = {"dtype": "f64", "value": samples / elapsed / 1e6, "unit": "Msamples/s", "steps": args.f64_steps,
+           "ms_per_step": elapsed / args.f64_steps * 1e3, "setup_s": t_setup,
+           "kernel_ms": {k: acc[k] for k in ("ms_trace_closest", "ms_trace_shadow", "ms_shade", "ms_other", "ms_total")},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_ray": bpr, "avg_launch_ms": avg_ms,
+                        "launches": n_launch, "node_bytes": cc["node_bytes"]}}
+    return ref, parity
+
+
 def main():
     args = parse_args()
     import torch
@@ -157,7 +235,8 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     t0 = time.time()
-    spp_total = args.spp * world  # weak scaling: per-GPU samples fixed
+    strong = args.config == 3
+    spp_total = args.spp if strong else args.spp * world  # weak scaling: per-GPU samples fixed; configs[3]: total fixed
     if args.instanced:
         n_inst, n_tri = (int(x) for x in args.instanced.split("x"))
         sd = scenes.instanced_scene(n_inst, n_tri, args.width, args.height, spp=spp_total, max_depth=args.max_depth)
@@ -220,15 +299,18 @@ def main():
         avg_ms = acc["ms_trace_closest"] / n_launch
         bytes_per_launch = bytes_per_ray * acc["rays_closest"] / n_launch
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic, traffic_source = measured_traffic(args)
         line = {
             "metric": "Msamples/s (camera paths/s: rays traced x spp / s), 1M-tri soup",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{args.instanced} instances x triangles (flattened, 7 BSDFs round-robin)" if args.instanced else
                                     f"procedural {args.tris}-triangle soup ({args.materials} materials)")
                                    + " in 5-wall box + 1 quad area light, "
-                                   f"{args.width}x{args.height}, {args.spp} spp per GPU ({spp_total} total), max_depth "
+                                   f"{args.width}x{args.height}, "
+                                   + (f"{spp_total} spp total (BASELINE configs[3], rows sharded over the ranks)" if strong
+                                      else f"{args.spp} spp per GPU ({spp_total} total)") + ", max_depth "
                                    f"{args.max_depth}, no Russian roulette, "
                                    + ("procedural sky env-map 2048x1024, importance-sampled (extension)" if args.envmap
                                       else "constant background (no env-map IBL upstream)"),
@@ -240,11 +322,23 @@ def main():
                        "kernel_ms": {k: acc[k] for k in ("ms_trace_closest", "ms_trace_shadow", "ms_shade", "ms_other",
                                                          "ms_total")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "achieved_is": "algorithmic bytes (node_visits x node bytes + prim_tests x 48 B + ray state) per "
+                                        "launch / launch time; mostly served by L2 / Infinity Cache — the kernel is "
+                                        "VALU-issue-bound (DESIGN.md §7), `traffic` is what reaches the fabric",
                          "kernel": "tk::k_trace_group<float,2,false,false,PathIo<float>,true> (closest hit, pair kernel, compressed nodes)", "launches": n_launch,
                          "avg_launch_ms": avg_ms, "bytes_per_ray": bytes_per_ray,
                          "rays_per_launch": acc["rays_closest"] / n_launch},
         }
+        if world == 1 and args.f64_steps > 0:
+            # the same workload at the reference's precision (Real = double, src/take.h:27): the f32 scene is closed
+            # first so that the f64 path state (256 B per path) gets the HBM
+            img32 = out.to(torch.float64).clone()  # the image of the last timed f32 step (seed 0, args.spp samples)
+            scene.close()
+            del out
+            torch.cuda.empty_cache()
+            line["reference_precision"], line["parity"] = f64_leg(args, sd, img32, stream)
+            scene = None
         if world == 1 and not args.no_cpu_baseline and not args.instanced:
             try:
                 line["cpu_baseline"] = cpu_baseline(args, sd)
@@ -253,7 +347,8 @@ def main():
                                         "sample": f"failed: {e}"}
         assert img is not None and torch.isfinite(img).all()
         print(json.dumps(line), flush=True)
-    scene.close()
+    if scene is not None:
+        scene.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -7,6 +7,7 @@ c_float3 = C.c_float * 3
 
 TAKE_PRECISION_F32 = 0
 TAKE_PRECISION_F64 = 1
+TAKE_OK, TAKE_E_INVALID, TAKE_E_DEVICE, TAKE_E_NO_GPU, TAKE_E_NOMEM = 0, -1, -2, -3, -4
 
 MAT_DIFFUSE, MAT_MIRROR, MAT_PLASTIC, MAT_PHONG, MAT_BLINN_PHONG, MAT_BLINN_PHONG_MICROFACET = range(6)
 MAT_DISNEY_DIFFUSE, MAT_DISNEY_METAL, MAT_DISNEY_GLASS, MAT_DISNEY_CLEARCOAT, MAT_DISNEY_SHEEN, MAT_DISNEY_BSDF = range(6, 12)

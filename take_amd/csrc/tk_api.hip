@@ -35,14 +35,35 @@ int fail(int code, const std::string &msg) {
             return fail(TAKE_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));             \
     } while (0)
 
+// Fault injection for the allocation-failure tests (tests/test_gpu_robustness.py): TAKE_HIP_FAIL_ALLOC=<k> makes the
+// k-th device allocation after the variable was (re)set fail with hipErrorOutOfMemory.  A real out-of-memory cannot
+// be provoked reliably from a test: the driver over-commits, a 300 GB request on a 288 GB device succeeded.
+inline bool inject_alloc_failure() {
+    static std::string seen;
+    static long calls = 0;
+    const char *e = std::getenv("TAKE_HIP_FAIL_ALLOC");
+    if (!e || !*e) {
+        seen.clear();
+        return false;
+    }
+    if (seen != e) seen = e, calls = 0;
+    return ++calls == std::atol(e);
+}
+
 template <class T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
     hipError_t alloc(size_t count) {
-        release();
-        n = count;
+        release();  // p = nullptr, n = 0: the state a failed allocation leaves behind
         if (count == 0) return hipSuccess;
-        return hipMalloc((void **)&p, count * sizeof(T));
+        const hipError_t e = inject_alloc_failure() ? hipErrorOutOfMemory : hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            (void)hipGetLastError();  // the error is reported through the return value, not left sticky
+            return e;
+        }
+        n = count;
+        return hipSuccess;
     }
     hipError_t upload(const std::vector<T> &v) {
         hipError_t e = alloc(v.size());
@@ -62,8 +83,8 @@ struct EventPool {
     size_t used = 0;
     hipEvent_t get() {
         if (used == ev.size()) {
-            hipEvent_t e;
-            (void)hipEventCreate(&e);
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;  // callers treat a null event as a failed timing call
             ev.push_back(e);
         }
         return ev[used++];
@@ -300,6 +321,14 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
         else HIP_TRY(sc.nodes.upload(h.nodes));
     }
     sc.built_on_device = on_device;
+    // the trace kernels address nodes and primitive records with 32-bit byte offsets (full-rate integer math)
+    {
+        const uint64_t node_bytes = (uint64_t)h.stats.n_nodes * (use_q ? sizeof(QNode4) : sizeof(Node4<R>));
+        const uint64_t prim_bytes = (uint64_t)sc.prims.n * sizeof(PrimRec<R>);
+        if (node_bytes >= (1ull << 32) || prim_bytes >= (1ull << 32))
+            return fail(TAKE_E_INVALID, "scene too large for the 32-bit record offsets of the trace kernels (" +
+                                            std::to_string(sc.prims.n) + " primitives, " + std::to_string(h.stats.n_nodes) + " nodes)");
+    }
     HIP_TRY(sc.shapes.upload(h.shapes));
     HIP_TRY(sc.meshes.upload(h.meshes));
     HIP_TRY(sc.face_idx.upload(h.face_idx));
@@ -343,9 +372,7 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 4, false, false, PathIo<R>>, TQ_BLOCK, 0));
         groups_per_block = GroupGeom<4>::GROUPS, spill_levels = GroupGeom<4>::SPILL;
     } else if (sc.group == 2) {
-        if constexpr (sizeof(R) == 4) {
-            if (use_q) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>, true>, TQ_BLOCK, 0));
-        }
+        if (use_q) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>, true>, TQ_BLOCK, 0));
         if (!use_q) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>>, TQ_BLOCK, 0));
         groups_per_block = GroupGeom<2>::GROUPS, spill_levels = GroupGeom<2>::SPILL;
     } else {
@@ -359,19 +386,32 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     return TAKE_OK;
 }
 
+// Path-state / queue / framebuffer workspace of a scene, grown on demand.  A failed allocation leaves the scene
+// WITHOUT a workspace (capacity 0, every buffer released) and returns TAKE_E_NOMEM: the next render allocates afresh
+// instead of trusting a stale capacity over null pointers.
+template <class R> void release_workspace(SceneT<R> &sc) {
+    sc.state_r.release(), sc.queue[0].release(), sc.queue[1].release(), sc.shadow_queue.release();
+    sc.sorted_queue.release(), sc.sort_keys.release();
+    sc.capacity = 0;
+}
 template <class R> int ensure_workspace(SceneT<R> &sc, int64_t slots, int64_t npix) {
     if (slots > sc.capacity) {
-        HIP_TRY(sc.state_r.alloc((size_t)PATH_REC * slots));
-        HIP_TRY(sc.queue[0].alloc(slots));
-        HIP_TRY(sc.queue[1].alloc(slots));
-        HIP_TRY(sc.shadow_queue.alloc(slots));
-        HIP_TRY(sc.sorted_queue.alloc(slots));
-        HIP_TRY(sc.sort_keys.alloc(slots));
+        release_workspace(sc);
+        const bool ok = sc.state_r.alloc((size_t)PATH_REC * slots) == hipSuccess && sc.queue[0].alloc(slots) == hipSuccess &&
+                        sc.queue[1].alloc(slots) == hipSuccess && sc.shadow_queue.alloc(slots) == hipSuccess &&
+                        sc.sorted_queue.alloc(slots) == hipSuccess && sc.sort_keys.alloc(slots) == hipSuccess;
+        if (!ok) {
+            release_workspace(sc);
+            return fail(TAKE_E_NOMEM, "out of device memory for " + std::to_string(slots) + " path slots (" +
+                                          std::to_string((size_t)slots * (PATH_REC * sizeof(R) + 17) >> 20) + " MiB)");
+        }
         sc.capacity = slots;
     }
     if ((int64_t)sc.accum.n < 3 * npix) {
-        HIP_TRY(sc.accum.alloc(3 * npix));
-        HIP_TRY(sc.out.alloc(3 * npix));
+        if (sc.accum.alloc(3 * npix) != hipSuccess || sc.out.alloc(3 * npix) != hipSuccess) {
+            sc.accum.release(), sc.out.release();
+            return fail(TAKE_E_NOMEM, "out of device memory for the framebuffer");
+        }
     }
     return TAKE_OK;
 }
@@ -404,15 +444,19 @@ struct Timer {
     TakeScene *ts;
     hipStream_t stream;
     bool on;
+    hipError_t err = hipSuccess;  // first failure of an event call; render_impl reports it instead of bogus times
     void begin(int which) {
         if (!on) return;
         hipEvent_t a = ts->events.get(), b = ts->events.get();
-        (void)hipEventRecord(a, stream);
+        const hipError_t e = (a && b) ? hipEventRecord(a, stream) : hipErrorOutOfMemory;
+        if (e != hipSuccess && err == hipSuccess) err = e;
         ts->timed.push_back({which, {a, b}});
     }
     void end() {
         if (!on) return;
-        (void)hipEventRecord(ts->timed.back().second.second, stream);
+        const hipEvent_t b = ts->timed.back().second.second;
+        const hipError_t e = b ? hipEventRecord(b, stream) : hipErrorOutOfMemory;
+        if (e != hipSuccess && err == hipSuccess) err = e;
     }
 };
 
@@ -432,14 +476,12 @@ void launch_trace(int group, bool any, bool count, dim3 grid, hipStream_t stream
         else if (count) TK_LAUNCH(G, false, true);         \
         else TK_LAUNCH(G, false, false);                   \
     } while (0)
-    if constexpr (sizeof(R) == 4) {
-        if (group == 2 && dev.qnodes) {  // compressed nodes
-            if (any && count) TK_LAUNCH_Q(2, true, true, true);
-            else if (any) TK_LAUNCH_Q(2, true, false, true);
-            else if (count) TK_LAUNCH_Q(2, false, true, true);
-            else TK_LAUNCH_Q(2, false, false, true);
-            return;
-        }
+    if (group == 2 && dev.qnodes) {  // compressed nodes (both precisions)
+        if (any && count) TK_LAUNCH_Q(2, true, true, true);
+        else if (any) TK_LAUNCH_Q(2, true, false, true);
+        else if (count) TK_LAUNCH_Q(2, false, true, true);
+        else TK_LAUNCH_Q(2, false, false, true);
+        return;
     }
     if (group == 4) TK_LAUNCH_G(4);
     else if (group == 2) TK_LAUNCH_G(2);
@@ -651,6 +693,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     HIP_TRY(hipEventRecord(ev_end, stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));
+    if (tm.err != hipSuccess) return fail(TAKE_E_DEVICE, std::string("kernel timing events: ") + hipGetErrorString(tm.err));
 
     unsigned long long c[C_NUM_WORDS];
     HIP_TRY(hipMemcpy(c, sc.counters.p, sizeof c, hipMemcpyDeviceToHost));
@@ -723,6 +766,11 @@ int trace_impl(TakeScene *ts, const void *d_rays, int64_t n, void *d_hits, int32
 
 template <class R> int trace_host(TakeScene *ts, const void *rays, int64_t n, void *hits, int32_t *occ, bool any) {
     if (n == 0) return TAKE_OK;
+    // entry distances are ordered through their bit patterns (non-negative floats): a ray must start at tmin >= 0
+    for (int64_t i = 0; i < n; i++) {
+        const RayAoS<R> &q = ((const RayAoS<R> *)rays)[i];
+        if (!(q.tmin >= R(0))) return fail(TAKE_E_INVALID, "ray " + std::to_string(i) + ": tmin must be >= 0");
+    }
     DevBuf<RayAoS<R>> d_rays;
     DevBuf<HitAoS<R>> d_hits;
     DevBuf<int32_t> d_occ;
@@ -746,6 +794,24 @@ template <class R> int trace_host(TakeScene *ts, const void *rays, int64_t n, vo
     d_rays.release(), d_hits.release(), d_occ.release();
     return rc;
 }
+
+// A scene lives on the device that was current when it was created; every entry point that touches it makes that
+// device current for the duration of the call and restores the caller's afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+#define TAKE_ON_DEVICE(ts)                                                                            \
+    DeviceGuard guard_((ts)->device);                                                                 \
+    if (!guard_.ok) return fail(TAKE_E_DEVICE, "cannot make the scene's device current")
 
 int check_device() {
     int n = 0;
@@ -800,6 +866,7 @@ int take_hip_scene_create(const TakeSceneDesc *desc, const TakeBuildOpts *opts, 
 
 int take_hip_scene_destroy(TakeScene *ts) {
     if (!ts) return TAKE_OK;
+    DeviceGuard guard_(ts->device);
     ts->f.release();
     ts->d.release();
     ts->events.destroy();
@@ -817,12 +884,14 @@ int take_hip_render_rows(const TakeScene *ts, int32_t strip_first, int32_t strip
 
 int take_hip_render_device(TakeScene *ts, const TakeRenderOpts *opts, void *d_rgb_out, void *stream) {
     if (!ts || !opts || !d_rgb_out) return fail(TAKE_E_INVALID, "null argument");
+    TAKE_ON_DEVICE(ts);
     if (ts->precision == TAKE_PRECISION_F64) return render_impl<double>(ts, *opts, d_rgb_out, (hipStream_t)stream);
     return render_impl<float>(ts, *opts, d_rgb_out, (hipStream_t)stream);
 }
 
 int take_hip_render(TakeScene *ts, const TakeRenderOpts *opts, void *rgb_out_host) {
     if (!ts || !opts || !rgb_out_host) return fail(TAKE_E_INVALID, "null argument");
+    TAKE_ON_DEVICE(ts);
     const bool f64 = ts->precision == TAKE_PRECISION_F64;
     const int W = f64 ? ts->d.host.cam.width : ts->f.host.cam.width;
     const int stride = opts->strip_stride > 0 ? opts->strip_stride : 1;
@@ -848,11 +917,13 @@ int take_hip_render(TakeScene *ts, const TakeRenderOpts *opts, void *rgb_out_hos
 
 int take_hip_trace_closest(TakeScene *ts, const void *rays, int64_t n, void *hits) {
     if (!ts || (n > 0 && (!rays || !hits))) return fail(TAKE_E_INVALID, "null argument");
+    TAKE_ON_DEVICE(ts);
     return ts->precision == TAKE_PRECISION_F64 ? trace_host<double>(ts, rays, n, hits, nullptr, false)
                                                : trace_host<float>(ts, rays, n, hits, nullptr, false);
 }
 int take_hip_trace_any(TakeScene *ts, const void *rays, int64_t n, int32_t *occluded) {
     if (!ts || (n > 0 && (!rays || !occluded))) return fail(TAKE_E_INVALID, "null argument");
+    TAKE_ON_DEVICE(ts);
     return ts->precision == TAKE_PRECISION_F64 ? trace_host<double>(ts, rays, n, nullptr, occluded, true)
                                                : trace_host<float>(ts, rays, n, nullptr, occluded, true);
 }
@@ -860,6 +931,7 @@ int take_hip_trace_closest_device(TakeScene *ts, const void *d_rays, int64_t n, 
                                   void *stream) {
     if (!ts || (n > 0 && (!d_rays || !d_hits))) return fail(TAKE_E_INVALID, "null argument");
     if (n == 0) return TAKE_OK;
+    TAKE_ON_DEVICE(ts);
     return ts->precision == TAKE_PRECISION_F64
                ? trace_impl<double>(ts, d_rays, n, d_hits, nullptr, false, count_mode != 0, (hipStream_t)stream)
                : trace_impl<float>(ts, d_rays, n, d_hits, nullptr, false, count_mode != 0, (hipStream_t)stream);
@@ -892,9 +964,12 @@ int take_hip_debug_table(int32_t kind, int32_t precision, const double *in, int6
             rc = fail(TAKE_E_NOMEM, "debug table allocation failed");
             break;
         }
-        (void)hipMemcpy(d_in.p, in, d_in.bytes(), hipMemcpyHostToDevice);
-        (void)hipMemcpy(d_rnd.p, rnd, d_rnd.bytes(), hipMemcpyHostToDevice);
-        (void)hipMemset(d_out.p, 0, d_out.bytes());
+        if (hipMemcpy(d_in.p, in, d_in.bytes(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_rnd.p, rnd, d_rnd.bytes(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(d_out.p, 0, d_out.bytes()) != hipSuccess) {
+            rc = fail(TAKE_E_DEVICE, "debug table upload failed");
+            break;
+        }
         const dim3 g((unsigned)((n + BLOCK - 1) / BLOCK)), b(BLOCK);
         if (precision == TAKE_PRECISION_F64) {
             DeviceScene<double> sc{};

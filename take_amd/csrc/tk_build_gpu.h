@@ -217,6 +217,16 @@ __global__ void __launch_bounds__(BLK) k_collapse(int level, const int *__restri
                 kids[nk++] = g.y;
             }
             for (int i = 0; i < nk; i++) n_int += kids[i] >= 0;
+            // slot order = visiting order of the (unranked) shadow-ray traversal: largest box first (tk_bvh.h)
+            float ar[4];
+            for (int i = 0; i < nk; i++) ar[i] = half_area(kids[i] >= 0 ? ibox[kids[i]] : lbox[~kids[i]]);
+            for (int i = 1; i < nk; i++)
+                for (int j = i; j > 0 && ar[j] > ar[j - 1]; j--) {
+                    const float ta = ar[j];
+                    ar[j] = ar[j - 1], ar[j - 1] = ta;
+                    const int tk = kids[j];
+                    kids[j] = kids[j - 1], kids[j - 1] = tk;
+                }
         }
         // wave-aggregated allocation of the interior children on the next level
         int incl = n_int;

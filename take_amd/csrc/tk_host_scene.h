@@ -18,7 +18,7 @@ namespace tk {
 
 template <class R> struct HostScene {
     std::vector<Node4<R>> nodes;
-    std::vector<QNode4> qnodes;  // f32: compressed copy of nodes (empty = not in use)
+    std::vector<QNode4> qnodes;  // compressed copy of nodes (empty = not in use)
     float grid_lo[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1};
     double q_inflation = 1.0;    // mean surface-area inflation of the compressed child boxes (1 = none)
     std::vector<PrimRec<R>> prims;
@@ -371,14 +371,15 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
         const int root = builder.build();
         hs.root_child = collapse_to_wide<R>(builder.nodes(), root, hs.nodes, order, hs.stats);
         hs.qnodes.clear();
-        if constexpr (sizeof(R) == 4) {
-            // f32 scenes traverse the 64-byte compressed nodes unless the 16-bit scene grid is too coarse for the
+        {
+            // Both precisions traverse the 64-byte compressed nodes unless the 16-bit scene grid is too coarse for the
             // geometry (child boxes growing by more than 10 % in area on average: a scene mixing scales by >1e4), or on request
-            // (TAKE_HIP_NODES=wide / =q16: A/B runs)
+            // (TAKE_HIP_NODES=wide / =q16: A/B runs).  In f64 scenes only the box tests use them (conservative, so
+            // exactness is not at stake); hits are decided by the double-precision primitive tests.
             const char *fmt = std::getenv("TAKE_HIP_NODES");
             const std::string f = fmt ? fmt : "";
             if (f != "wide" && !hs.nodes.empty()) {
-                hs.q_inflation = quantise_nodes(hs.nodes, hs.qnodes, hs.grid_lo, hs.grid_step);
+                hs.q_inflation = quantise_nodes<R>(hs.nodes, hs.qnodes, hs.grid_lo, hs.grid_step);
                 if (hs.q_inflation > 1.10 && f != "q16") hs.qnodes.clear();
             }
         }

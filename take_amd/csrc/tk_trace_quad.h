@@ -168,7 +168,7 @@ template <int G> __device__ __forceinline__ int group_max_i(int v) {
     return v;
 }
 
-// QN: traverse the 64-byte compressed nodes (sc.qnodes; f32 pairs only) instead of the 128-byte ones.
+// QN: traverse the 64-byte compressed nodes (sc.qnodes; pairs only) instead of the full-width ones.
 template <class R, int G, bool ANY_HIT, bool COUNT, class Io, bool QN = false>
 __global__ void __launch_bounds__(TQ_BLOCK, sizeof(R) == 8 ? 4 : TQ_MIN_WAVES)  // f64 (parity mode): room for the wider state
 k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_t n_direct, int32_t *head,
@@ -186,7 +186,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
     const int32_t n = n_ptr ? *n_ptr : n_direct;
     if (blockIdx.x == 0 && threadIdx.x == 0 && counter_word >= 0)
         atomicAdd(&counters[counter_word], (unsigned long long)n);
-    static_assert(!QN || (G == 2 && sizeof(R) == 4), "compressed nodes: f32 pair kernel only");
+    static_assert(!QN || G == 2, "compressed nodes: pair kernel only");
     const char *const node_base = QN ? (const char *)sc.qnodes : (const char *)sc.nodes;
     const char *const prim_base = (const char *)sc.prims;
 
@@ -197,6 +197,11 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
     RayT<R> ray{};
     R idx = R(0), idy = R(0), idz = R(0), tbest = R(0);
     QRay qr{};  // QN: the ray in grid space (replaces idx/idy/idz, which are dead then)
+    // QN in f64: the box tests run in f32 on the compressed nodes (conservative, so precision is not at stake; hits are
+    // decided by the double-precision primitive tests) — the limits enter them rounded outwards
+    float tmin_f = 0.0f, tbest_f = 0.0f;
+    auto lim_lo = [&]() -> float { if constexpr (sizeof(R) == 4) return (float)ray.tmin; else return tmin_f; };
+    auto lim_hi = [&]() -> float { if constexpr (sizeof(R) == 4) return (float)tbest; else return tbest_f; };
     int32_t tag = 0;            // path slot (render) / ray index (trace hooks) of the ray in this slot
     int sp = 0;                 // entries on this group's stack
     int32_t cur = CHILD_EMPTY;  // >= 0: at an interior node; < 0: at a leaf; CHILD_EMPTY: the slot holds no ray
@@ -301,6 +306,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                         idx = safe_inv(ray.d.x), idy = safe_inv(ray.d.y), idz = safe_inv(ray.d.z);
                         if constexpr (QN) qr = qray_make(sc.grid_lo, sc.grid_step, ray.o, idx, idy, idz);
                         tbest = ray.tmax;
+                        if constexpr (QN && sizeof(R) == 8) tmin_f = stack_key(ray.tmin), tbest_f = float_above(tbest);
                         sp = 0;
                         my_t = Const<R>::inf();
                         my_prim = -1;
@@ -344,8 +350,8 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                     for (int j = 0; j < CPL; j++) {
                         const uint4 c = *(const uint4 *)(node_base + off + j * (uint32_t)sizeof(QChild));
                         float tn;
-                        const bool ok = qbox_test(qr, c.x, c.y, c.z, (int32_t)c.w, ray.tmin, tbest, tn);
-                        key[j] = ok ? ((__float_as_uint(tn * Const<float>::BOX_SHRINK) & ~3u) | (uint32_t)(gl * CPL + j))
+                        const bool ok = qbox_test(qr, c.x, c.y, c.z, (int32_t)c.w, lim_lo(), lim_hi(), tn);
+                        key[j] = ok ? ((__float_as_uint(tn * Const<float>::BOX_SHRINK) & ~3u) | (uint32_t)(3 - (gl * CPL + j)))
                                     : TQ_KEY_INVALID;
                         child[j] = (int32_t)c.w;
                     }
@@ -359,9 +365,11 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                         R tn;
                         const bool ok = box_test(c, ray.o, idx, idy, idz, ray.tmin, tbest, tn);
                         // order key: the (shrunk, hence conservative) entry distance as an integer — non-negative
-                        // floats order like their bit patterns — with the slot number in the two low bits, which
-                        // makes the four keys of a node distinct
-                        key[j] = ok ? ((__float_as_uint(stack_key(tn * Const<R>::BOX_SHRINK)) & ~3u) | (uint32_t)(gl * CPL + j))
+                        // floats order like their bit patterns — with 3 - slot number in the two low bits, which
+                        // makes the four keys of a node distinct and sends equal distances (every box that contains
+                        // the ray origin enters at tmin) to the LAST slot first: slots are stored largest box first
+                        // (tk_bvh.h, for the shadow rays), and the smallest box is the likeliest to give a near hit
+                        key[j] = ok ? ((__float_as_uint(stack_key(tn * Const<R>::BOX_SHRINK)) & ~3u) | (uint32_t)(3 - (gl * CPL + j)))
                                     : TQ_KEY_INVALID;
                         child[j] = c.child;
                     }
@@ -480,6 +488,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                     }
                 }
                 tbest = tk_fmin(tbest, group_min<G>(my_t));
+                if constexpr (QN && sizeof(R) == 8) tbest_f = float_above(tbest);
                 bool finished = ANY_HIT ? (group_max_i<G>(my_prim) >= 0) : false;
                 if (!finished) finished = advance();
                 if (finished) finish();

@@ -85,6 +85,22 @@ TK_HD float stack_key(double t) {  // largest float <= t: keeps pop-time culling
     return f;
 }
 
+// smallest float >= t (t >= 0 or +inf): the f32 image of a double far limit that keeps a box test conservative
+TK_HD float float_above(float t) { return t; }
+TK_HD float float_above(double t) {
+    float f = (float)t;
+    if ((double)f < t) {
+        union {
+            float f;
+            uint32_t u;
+        } b;
+        b.f = f;
+        b.u = f > 0.0f ? b.u + 1u : (f < 0.0f ? b.u - 1u : 0x00000001u);
+        f = b.f;
+    }
+    return f;
+}
+
 // Conservative slab test of one child slot: true when [tmin, tbest] can overlap the box.  Both planes are widened
 // by a few ulp (t >= tmin > 0 on this path, so the scaling is monotone), which keeps closest-hit results
 // independent of the tree shape.  tn = entry distance (the traversal order key).
@@ -114,6 +130,16 @@ TK_HD QRay qray_make(const float *grid_lo, const float *grid_step, Vec3<float> o
     f.bx = idx * grid_step[0], f.by = idy * grid_step[1], f.bz = idz * grid_step[2];
     return f;
 }
+// f64 rays traverse the same compressed nodes with the same f32 slab test: A and B are formed in double and rounded
+// to float once (half the rounding of the f32 route above, which the builder's slack and BOX_SHRINK / BOX_GROW
+// already cover); the limits tmin / tbest enter the test rounded outwards (stack_key, float_above).
+TK_HD QRay qray_make(const float *grid_lo, const float *grid_step, Vec3<double> o, double idx, double idy, double idz) {
+    QRay f;
+    f.ax = (float)(((double)grid_lo[0] - o.x) * idx), f.ay = (float)(((double)grid_lo[1] - o.y) * idy),
+    f.az = (float)(((double)grid_lo[2] - o.z) * idz);
+    f.bx = (float)(idx * (double)grid_step[0]), f.by = (float)(idy * (double)grid_step[1]), f.bz = (float)(idz * (double)grid_step[2]);
+    return f;
+}
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef float tk_f2 __attribute__((ext_vector_type(2)));
 // both planes of one axis in one packed fma (v_pk_fma_f32): same value per element as the scalar form below
@@ -140,7 +166,7 @@ TK_HD bool qbox_test(const QRay &f, uint32_t qx, uint32_t qy, uint32_t qz, int32
 }
 
 struct TravCount {
-    uint32_t nodes = 0, prims = 0;
+    uint32_t nodes = 0, prims = 0, leaves = 0;
 };
 
 // Stack concept: void push(int level, int32_t child, float key); void pop(int level, int32_t&, float&)
@@ -154,9 +180,12 @@ TK_HD void traverse(const DeviceScene<R> &sc, const RayT<R> &ray, Stack &stack, 
     const R idx = safe_inv(ray.d.x), idy = safe_inv(ray.d.y), idz = safe_inv(ray.d.z);
     R tbest = ray.tmax;
     QRay qr{};
-    if (sizeof(R) == 4 && sc.qnodes)
-        qr = qray_make(sc.grid_lo, sc.grid_step, Vec3<float>{(float)ray.o.x, (float)ray.o.y, (float)ray.o.z}, (float)idx,
-                       (float)idy, (float)idz);
+    if (sc.qnodes) qr = qray_make(sc.grid_lo, sc.grid_step, ray.o, idx, idy, idz);
+    const float tmin_f = stack_key(ray.tmin);  // largest float <= tmin
+    const bool qn = sc.qnodes != nullptr;
+    // conservative float image of an entry distance (the stack's culling key): the compressed test computes in f32
+    // whatever R is, so its margin is the f32 one
+    auto cull_key = [&](R k) -> float { return qn ? (float)k * Const<float>::BOX_SHRINK : stack_key(k * Const<R>::BOX_SHRINK); };
     int sp = 0;
     int32_t cur = sc.root_child;
     for (;;) {
@@ -164,12 +193,12 @@ TK_HD void traverse(const DeviceScene<R> &sc, const RayT<R> &ray, Stack &stack, 
             if (COUNT) tc.nodes++;
             R key[4];
             int32_t ch[4];
-            if (sizeof(R) == 4 && sc.qnodes) {  // compressed nodes (f32 scenes only: qnodes is null otherwise)
+            if (qn) {  // compressed nodes
                 const QNode4 &n = sc.qnodes[cur];
+                const float tbest_f = float_above(tbest);
                 for (int i = 0; i < 4; i++) {
                     float tn;
-                    const bool ok = qbox_test(qr, n.c[i].q[0], n.c[i].q[1], n.c[i].q[2], n.c[i].child, (float)ray.tmin,
-                                              (float)tbest, tn);
+                    const bool ok = qbox_test(qr, n.c[i].q[0], n.c[i].q[1], n.c[i].q[2], n.c[i].child, tmin_f, tbest_f, tn);
                     key[i] = ok ? (R)tn : Const<R>::inf();
                     ch[i] = n.c[i].child;
                 }
@@ -183,10 +212,27 @@ TK_HD void traverse(const DeviceScene<R> &sc, const RayT<R> &ray, Stack &stack, 
                     ch[i] = n.c[i].child;
                 }
             }
-            // sorting network, ascending by entry distance
+            if (ANY_HIT) {
+                // shadow rays: the order of the trace kernel's any-hit instance (tk_trace_quad.h) — no ranking, the
+                // first hit slot is visited next, the others are popped last slot first
+                int first = -1;
+                for (int i = 0; i < 4; i++)
+                    if (key[i] < Const<R>::inf()) {
+                        if (first < 0) first = i;
+                        else stack.push(sp++, ch[i], cull_key(key[i]));
+                    }
+                if (first >= 0) {
+                    cur = ch[first];
+                    continue;
+                }
+                goto pop_next;
+            }
+            // sorting network, ascending by entry distance; equal distances (boxes that contain the ray origin all
+            // enter at tmin) go to the LATER slot first: slots are stored largest box first (tk_bvh.h), and the
+            // smallest box is the one most likely to yield a close hit that prunes the others
 #define TK_CSWAP(a, b)                        \
     {                                         \
-        bool sw = key[b] < key[a];            \
+        bool sw = key[b] <= key[a];           \
         R ka = sw ? key[b] : key[a];          \
         R kb = sw ? key[a] : key[b];          \
         int32_t ca = sw ? ch[b] : ch[a];      \
@@ -196,15 +242,16 @@ TK_HD void traverse(const DeviceScene<R> &sc, const RayT<R> &ray, Stack &stack, 
             TK_CSWAP(0, 1) TK_CSWAP(2, 3) TK_CSWAP(0, 2) TK_CSWAP(1, 3) TK_CSWAP(1, 2)
 #undef TK_CSWAP
             // far to near: deferred children go on the stack, the nearest is visited next
-            if (key[3] < Const<R>::inf()) stack.push(sp++, ch[3], stack_key(key[3] * Const<R>::BOX_SHRINK));
-            if (key[2] < Const<R>::inf()) stack.push(sp++, ch[2], stack_key(key[2] * Const<R>::BOX_SHRINK));
-            if (key[1] < Const<R>::inf()) stack.push(sp++, ch[1], stack_key(key[1] * Const<R>::BOX_SHRINK));
+            if (key[3] < Const<R>::inf()) stack.push(sp++, ch[3], cull_key(key[3]));
+            if (key[2] < Const<R>::inf()) stack.push(sp++, ch[2], cull_key(key[2]));
+            if (key[1] < Const<R>::inf()) stack.push(sp++, ch[1], cull_key(key[1]));
             if (key[0] < Const<R>::inf()) {
                 cur = ch[0];
                 continue;
             }
         } else if (cur != CHILD_EMPTY) {
             const int first = leaf_first(cur), cnt = leaf_count(cur);
+            if (COUNT) tc.leaves++;
             for (int k = 0; k < cnt; k++) {
                 const PrimRec<R> &p = sc.prims[first + k];
                 if (COUNT) tc.prims++;
@@ -224,6 +271,7 @@ TK_HD void traverse(const DeviceScene<R> &sc, const RayT<R> &ray, Stack &stack, 
             }
         }
         // pop the next deferred subtree that can still contain a closer hit
+    pop_next:
         for (;;) {
             if (sp == 0) return;
             float k;
