@@ -178,8 +178,17 @@ typedef struct TakeRenderOpts {
     int32_t strip_first;   /* multi-GPU: this rank renders the 4-row strips s with     */
     int32_t strip_stride;  /*   s % strip_stride == strip_first (1-GPU: 0 and 1)       */
     int32_t samples_per_batch; /* samples per pixel in flight at once; <=0: auto       */
-    int32_t reserved;
+    int32_t integrator;    /* which of the reference's integrators (src/integrator/path_tracing.h):
+                              0 path_tracing (:5, multi-sample MIS — what render() calls; the default),
+                              1 path_tracing_raw (:114), 2 path_tracing_one_sample_MIS (:161),
+                              3 path_tracing_one_sample_MIS_power (:274, lights picked by power:
+                              src/light.cpp:9-30).  1..3 are defined upstream but called by nothing there;
+                              they do not know the environment-map extension (TAKE_E_INVALID with one) */
 } TakeRenderOpts;
+#define TAKE_INTEGRATOR_PATH_MIS 0
+#define TAKE_INTEGRATOR_RAW 1
+#define TAKE_INTEGRATOR_ONE_SAMPLE_MIS 2
+#define TAKE_INTEGRATOR_ONE_SAMPLE_MIS_POWER 3
 
 typedef struct TakeScene TakeScene; /* opaque */
 

@@ -40,6 +40,9 @@ def lib():
         L.oracle_pt_mt.argtypes = [C.c_void_p, C.c_int, dp, C.c_int64, dp]
         L.oracle_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, dp, C.c_int]
         L.oracle_render.restype = C.c_double
+        L.oracle_pt_mt2.argtypes = [C.c_void_p, C.c_int, dp, C.c_int64, dp, C.c_int]
+        L.oracle_render2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, dp, C.c_int, C.c_int]
+        L.oracle_render2.restype = C.c_double
         L.oracle_get_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.oracle_counter_words.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
         _LIB = L
@@ -103,18 +106,20 @@ class OracleScene:
         lib().oracle_isect_brute(self.h, _dp(rays), rays.shape[0], _dp(out))
         return out
 
-    def pt_mt(self, max_depth, inp):
+    def pt_mt(self, max_depth, inp, integrator=0):
+        """one integrator call per row (org3 dir3 seed): radiance3 + the next random_real; `integrator` as in
+        TakeRenderOpts (0 path_tracing, 1 raw, 2 one-sample MIS, 3 one-sample MIS with power-based light picking)"""
         inp = np.ascontiguousarray(inp, np.float64)
         out = np.zeros((inp.shape[0], 4), np.float64)
-        lib().oracle_pt_mt(self.h, int(max_depth), _dp(inp), inp.shape[0], _dp(out))
+        lib().oracle_pt_mt2(self.h, int(max_depth), _dp(inp), inp.shape[0], _dp(out), int(integrator))
         return out
 
-    def render(self, spp, max_depth, rng_mode=RNG_COUNTER, seed=0, threads=None, counters=False):
+    def render(self, spp, max_depth, rng_mode=RNG_COUNTER, seed=0, threads=None, counters=False, integrator=0):
         """-> (H,W,3) float64 image (row 0 = top); self.seconds = tile-loop time"""
         threads = threads or os.cpu_count() or 1
         out = np.zeros((self.sd.height, self.sd.width, 3), np.float64)
-        self.seconds = lib().oracle_render(self.h, int(spp), int(max_depth), int(rng_mode), int(seed), int(threads),
-                                           _dp(out), int(counters))
+        self.seconds = lib().oracle_render2(self.h, int(spp), int(max_depth), int(rng_mode), int(seed), int(threads),
+                                            _dp(out), int(counters), int(integrator))
         return out
 
     def counters(self):

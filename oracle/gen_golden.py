@@ -345,6 +345,32 @@ def make_scene_goldens(names, man):
             man[f"pt-{name}-d{dd}"] = table(f"pt-{name}-d{dd}", np.hstack([o, d, seed]), xml, dd)
 
 
+INTEGRATOR_TABLES = {1: "ptraw", 2: "ptone", 3: "ptpow"}  # TakeRenderOpts.integrator -> table prefix
+
+
+def make_integrator_tables():
+    """The three integrators the reference defines but never calls (src/integrator/path_tracing.h:114 raw, :161
+    one-sample MIS, :274 one-sample MIS with power-based light picking) on the rays and seeds of the committed pt-*
+    tables: same inputs (pt-<scene>-d<depth>_in.f64), outputs <prefix>-<scene>-d<depth>_out.f64 = radiance3 +
+    the next random_real (draw count).  `python oracle/gen_golden.py integrators` adds them to the manifest without
+    touching the other fixtures."""
+    with open(os.path.join(GOLD, "manifest.json")) as f:
+        man = json.load(f)
+    for key in sorted(k for k in man if k.startswith("pt-")):
+        _, name, d = key.split("-")
+        depth = int(d[1:])
+        xml = os.path.join(SCENES, name + ".xml")
+        fin = os.path.join(TABLES, f"{key}_in.f64")
+        for mode, prefix in INTEGRATOR_TABLES.items():
+            fout = os.path.join(TABLES, f"{prefix}-{name}-{d}_out.f64")
+            run("pt", xml, depth, fin, fout, mode)
+            out = np.fromfile(fout, "<f8").reshape(-1, 4)
+            man[f"{prefix}-{name}-{d}"] = {"in": f"{key}_in.f64", "out_len": int(out.size),
+                                           "mean_radiance": float(out[:, :3].mean())}
+    with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+        json.dump(man, f, indent=1, sort_keys=True)
+
+
 def make_egress():
     """tests/golden/egress/: float images and the EXR files the reference's imwrite (tinyexr, half, ZIP) makes of them"""
     d = os.path.join(GOLD, "egress")
@@ -364,6 +390,9 @@ def main():
         raise SystemExit("oracle/_ref/ref_harness missing: run `make -C oracle ref` (needs /root/reference)")
     if sys.argv[1:] == ["egress"]:
         make_egress()
+        return
+    if sys.argv[1:] == ["integrators"]:
+        make_integrator_tables()
         return
     man = {}
     names = make_scene_files()

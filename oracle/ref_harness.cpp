@@ -6,7 +6,9 @@
 // It contains no reference code: it includes the reference's headers from where they lie
 // (-I/root/reference/src) and calls the reference's own functions:
 //   render()            src/render.cpp:9      (seed-patched at :60, see oracle/Makefile)
-//   path_tracing()      src/integrator/path_tracing.h:5
+//   path_tracing()      src/integrator/path_tracing.h:5, and the three integrators the reference defines but never
+//                       calls: path_tracing_raw :114, path_tracing_one_sample_MIS :161, .._power :274 (+ light_power()
+//                       src/light.cpp:25, with which the power tables the parser leaves empty are filled here)
 //   scene_intersect()   src/scene.cpp:25,  scene_occluded() src/scene.cpp:49
 //   intersect(BBox,Ray) src/bbox.h:18,     intersect_shape() src/shape.h:42
 //   construct_bvh()     src/bvh.cpp:8
@@ -33,8 +35,11 @@
 #include "take_flatten.hpp"
 #include "take_sceneio.hpp"
 
-// defined (non-inline) in the render.cpp translation unit via integrator/path_tracing.h
+// defined (non-inline) in the render.cpp translation unit via integrator/path_tracing.h (:5, :114, :161, :274)
 Vector3 path_tracing(const Scene &scene, const Ray &ray, std::mt19937 &rng);
+Vector3 path_tracing_raw(const Scene &scene, const Ray &ray, std::mt19937 &rng);
+Vector3 path_tracing_one_sample_MIS(const Scene &scene, const Ray &ray, std::mt19937 &rng);
+Vector3 path_tracing_one_sample_MIS_power(const Scene &scene, const Ray &ray, std::mt19937 &rng);
 
 static std::vector<double> read_f64(const std::string &path) {
     std::ifstream f(path, std::ios::binary | std::ios::ate);
@@ -348,15 +353,37 @@ int main(int argc, char **argv) {
         return 0;
     }
     if (cmd == "pt") {
-        // pt <scene.xml> <max_depth> <in: org3 dir3 seed (7)> <out: radiance3 next_random (4)>
+        // pt <scene.xml> <max_depth> <in: org3 dir3 seed (7)> <out: radiance3 next_random (4)> [integrator]
+        // integrator: 0 path_tracing (default), 1 path_tracing_raw, 2 path_tracing_one_sample_MIS,
+        //             3 path_tracing_one_sample_MIS_power
         Scene scene = load_scene(argv[2], atoi(argv[3]));
+        const int integrator = argc > 6 ? atoi(argv[6]) : 0;
+        if (integrator == 3) {
+            // Scene::lights_power_pmf / _cdf (src/scene.h:28-29) are read by sample_light_power / get_light_pmf
+            // (src/light.cpp:9-23) but no code of the reference fills them.  Filled here from the reference's own
+            // light_power() (src/light.cpp:25-30): pmf = power / sum, cdf = running sum starting at 0 (n + 1 entries,
+            // the layout sample_light_power's upper_bound expects).
+            Real total = 0;
+            std::vector<Real> power;
+            for (auto &l : scene.lights) power.push_back(light_power(scene, l)), total += power.back();
+            scene.lights_power_pmf.clear();
+            scene.lights_power_cdf.assign(1, Real(0));
+            for (Real p : power) {
+                scene.lights_power_pmf.push_back(p / total);
+                scene.lights_power_cdf.push_back(scene.lights_power_cdf.back() + p / total);
+            }
+        }
         auto in = read_f64(argv[4]);
         std::vector<double> o;
         for (size_t r = 0; r + 7 <= in.size(); r += 7) {
             const double *p = &in[r];
             Ray ray{V3(p), V3(p + 3), c_EPSILON, infinity<Real>()};
             std::mt19937 rng{(unsigned)p[6]};
-            push3(o, path_tracing(scene, ray, rng));
+            Vector3 L = integrator == 1   ? path_tracing_raw(scene, ray, rng)
+                        : integrator == 2 ? path_tracing_one_sample_MIS(scene, ray, rng)
+                        : integrator == 3 ? path_tracing_one_sample_MIS_power(scene, ray, rng)
+                                          : path_tracing(scene, ray, rng);
+            push3(o, L);
             o.push_back(random_real(rng));
         }
         write_f64(argv[5], o);

@@ -48,6 +48,9 @@ Image3<double> table_image() {  // the fixed 5x4 image of ref_harness.cpp "mater
 extern "C" {
 
 int oracle_abi_version(void) { return 1; }
+void oracle_pt_mt2(void *p, int max_depth, const double *in, int64_t n, double *out, int integrator);
+double oracle_render2(void *p, int spp, int max_depth, int rng_mode, uint64_t seed, int threads, double *out,
+                      int with_counters, int integrator);
 
 void oracle_tab_random_real(const double *in, int64_t n, double *out) {
     for (int64_t r = 0; r < n; r++) {
@@ -209,10 +212,12 @@ void *oracle_scene_create(const TakeSceneDesc *desc, int precision, double ray_e
         scene_from_desc(*desc, h->d);
         h->d.ray_eps = ray_eps > 0 ? ray_eps : 1e-7;
         build_bvh(h->d);
+        fill_light_power(h->d);
     } else {
         scene_from_desc(*desc, h->f);
         h->f.ray_eps = ray_eps > 0 ? (float)ray_eps : 1e-4f;
         build_bvh(h->f);
+        fill_light_power(h->f);
     }
     return h;
 }
@@ -269,28 +274,34 @@ void oracle_isect_brute(void *p, const double *rays, int64_t n, double *out) {
     }
 }
 // in: n x 7 (org3 dir3 seed) -> out: n x 4 (radiance3, next random_real); double + mt19937 only
-void oracle_pt_mt(void *p, int max_depth, const double *in, int64_t n, double *out) {
+void oracle_pt_mt(void *p, int max_depth, const double *in, int64_t n, double *out) { oracle_pt_mt2(p, max_depth, in, n, out, 0); }
+// the same with the integrator selectable (0 path_tracing, 1 raw, 2 one-sample MIS, 3 one-sample MIS by power)
+void oracle_pt_mt2(void *p, int max_depth, const double *in, int64_t n, double *out, int integrator) {
     Handle *h = (Handle *)p;
     for (int64_t r = 0; r < n; r++) {
         const double *q = in + 7 * r;
         Ray<double> ray{P3(q), P3(q + 3), K<double>::EPS, K<double>::inf()};
         MtRng rng((unsigned)q[6]);
-        put3(out + 4 * r, path_tracing(h->d, ray, rng, max_depth));
+        put3(out + 4 * r, integrate(integrator, h->d, ray, rng, max_depth));
         out[4 * r + 3] = rng.real();
     }
 }
 // out: H*W*3 doubles, image order.  Returns seconds spent in the tile loop.
 double oracle_render(void *p, int spp, int max_depth, int rng_mode, uint64_t seed, int threads, double *out,
                      int with_counters) {
+    return oracle_render2(p, spp, max_depth, rng_mode, seed, threads, out, with_counters, 0);
+}
+double oracle_render2(void *p, int spp, int max_depth, int rng_mode, uint64_t seed, int threads, double *out,
+                      int with_counters, int integrator) {
     Handle *h = (Handle *)p;
     h->counters = PathCounters{};
     auto t0 = std::chrono::steady_clock::now();
     if (h->precision == TAKE_PRECISION_F64) {
-        render(h->d, spp, max_depth, rng_mode, seed, threads, out, with_counters ? &h->counters : nullptr);
+        render(h->d, spp, max_depth, rng_mode, seed, threads, out, with_counters ? &h->counters : nullptr, integrator);
     } else {
         size_t n = (size_t)h->f.camera.width * h->f.camera.height * 3;
         std::vector<float> tmp(n);
-        render(h->f, spp, max_depth, RNG_COUNTER, seed, threads, tmp.data(), with_counters ? &h->counters : nullptr);
+        render(h->f, spp, max_depth, RNG_COUNTER, seed, threads, tmp.data(), with_counters ? &h->counters : nullptr, integrator);
         for (size_t i = 0; i < n; i++) out[i] = tmp[i];
     }
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -238,6 +238,10 @@ template <class R> struct Scene {
     EnvLight<R> env;
     std::vector<BVHNode<R>> bvh_nodes;
     int bvh_root = -1;
+    // Scene::lights_power_pmf / _cdf (scene.h:28-29): read by sample_light_power / get_light_pmf (light.cpp:9-23) but
+    // never filled by the reference.  Filled by fill_light_power() below from light_power() (light.cpp:25-30), the
+    // same recipe oracle/ref_harness.cpp applies to the reference's Scene for the `ptpow` golden tables.
+    std::vector<R> lights_power_pmf, lights_power_cdf;
     R ray_eps = K<R>::EPS;  // c_EPSILON in its ray-offset role (render.cpp:75, path_tracing.h:53,79)
 };
 
@@ -956,6 +960,175 @@ V3<R> path_tracing(const Scene<R> &sc, const Ray<R> &ray, Rng &rng, int max_dept
     return radiance;
 }
 
+// ------------------------------------------------------------------ src/light.cpp:9-30 (power-based light picking)
+template <class R> inline R luminance(V3<R> s) {  // vector.h:309-311
+    return s.x * R(0.212671) + s.y * R(0.715160) + s.z * R(0.072169);
+}
+template <class R> inline R light_power(const Scene<R> &sc, const Light<R> &l) {  // light.cpp:25-30
+    if (l.kind == 1) return luminance(l.intensity) * get_area(sc, sc.shapes[l.shape_id]) * K<R>::PI;
+    return 0;
+}
+template <class R> void fill_light_power(Scene<R> &sc) {
+    R total = 0;
+    std::vector<R> power;
+    for (auto &l : sc.lights) power.push_back(light_power(sc, l)), total += power.back();
+    sc.lights_power_pmf.clear();
+    sc.lights_power_cdf.assign(1, R(0));
+    for (R p : power) {
+        sc.lights_power_pmf.push_back(p / total);
+        sc.lights_power_cdf.push_back(sc.lights_power_cdf.back() + p / total);
+    }
+}
+template <class R, class Rng> int sample_light_power(const Scene<R> &sc, Rng &rng) {  // light.cpp:9-17
+    const std::vector<R> &cdf = sc.lights_power_cdf;
+    R u = Draw<R, Rng>::real(rng);
+    int size = (int)cdf.size() - 1;
+    const R *ptr = std::upper_bound(cdf.data(), cdf.data() + size + 1, u);
+    return std::clamp(int(ptr - cdf.data() - 1), 0, size - 1);
+}
+
+// ------------------------------------------------------------------ src/integrator/path_tracing.h:114-158
+// Path tracing without MIS (defined by the reference, called by nothing there).
+template <class R, class Rng>
+V3<R> path_tracing_raw(const Scene<R> &sc, const Ray<R> &ray, Rng &rng, int max_depth, PathCounters *pc = nullptr) {
+    Ray<R> r = ray;
+    auto v_ = scene_intersect(sc, r, pc ? &pc->closest : nullptr);
+    if (!v_) return sc.background;
+    Intersection<R> v = *v_;
+    V3<R> radiance{R(0), R(0), R(0)};
+    V3<R> throughput{R(1), R(1), R(1)};
+    for (int i = 0; i <= max_depth; ++i) {
+        if (pc) pc->bounces++;
+        if (v.area_light_id != -1) {
+            const Light<R> &light = sc.lights.at(v.area_light_id);
+            if (light.kind == 1) {
+                radiance = radiance + throughput * light.intensity;
+                break;
+            }
+        } else {
+            V3<R> dir_in = -r.dir;
+            const Material<R> &m = sc.materials[v.material_id];
+            auto rec_ = sample_bsdf(m, dir_in, v, sc, rng);
+            if (!rec_) break;
+            SampleRecord<R> &rec = *rec_;
+            V3<R> FG = eval_bsdf(m, dir_in, rec, v, sc);
+            V3<R> dir_out = normalize(rec.dir_out);
+            R pdf = rec.pdf;
+            if (pdf <= R(0)) break;
+            throughput = throughput * (FG / pdf);
+            r = Ray<R>{v.pos, dir_out, sc.ray_eps, K<R>::inf()};
+            auto nv = scene_intersect(sc, r, pc ? &pc->closest : nullptr);
+            if (!nv) {
+                radiance = radiance + throughput * sc.background;
+                break;
+            }
+            v = *nv;
+        }
+    }
+    return radiance;
+}
+
+// ------------------------------------------------------------------ src/integrator/path_tracing.h:161-271, :274-380
+// One-sample MIS: per vertex EITHER a light sample OR a BSDF sample (coin flip), one closest-hit ray either way, the
+// sampled direction weighted by the mixture density.  POWER = false: uniform light pick (path_tracing_one_sample_MIS);
+// POWER = true: pick by power (path_tracing_one_sample_MIS_power, "seems to have bugs" upstream — restated as written).
+// One undefined spot upstream: in the uniform variant the ray towards the sampled light point is dereferenced without
+// a check (`v = *v_`, :222; "we will always hit the light or an obstacle"); a miss ends the path here.
+template <class R, class Rng, bool POWER>
+V3<R> path_tracing_one_sample(const Scene<R> &sc, const Ray<R> &ray, Rng &rng, int max_depth, PathCounters *pc = nullptr) {
+    Ray<R> r = ray;
+    auto v_ = scene_intersect(sc, r, pc ? &pc->closest : nullptr);
+    if (!v_) return sc.background;
+    Intersection<R> v = *v_;
+    V3<R> radiance{R(0), R(0), R(0)};
+    V3<R> throughput{R(1), R(1), R(1)};
+    const R nlights = R(sc.lights.size());
+    for (int i = 0; i <= max_depth; ++i) {
+        if (pc) pc->bounces++;
+        if (v.area_light_id != -1) {
+            const Light<R> &light = sc.lights.at(v.area_light_id);
+            if (light.kind == 1) {
+                radiance = radiance + throughput * light.intensity;
+                break;
+            }
+        }
+        V3<R> dir_in = -r.dir;
+        const Material<R> &m = sc.materials[v.material_id];
+        bool is_specular = (m.tag == TAKE_MAT_PLASTIC || m.tag == TAKE_MAT_MIRROR);
+        if (sc.lights.size() > 0 && !is_specular && Draw<R, Rng>::real(rng) <= R(0.5)) {
+            // sampling a light
+            int light_id = POWER ? sample_light_power(sc, rng) : static_cast<int>(std::floor(Draw<R, Rng>::real(rng) * nlights));
+            const Light<R> &light = sc.lights[light_id];
+            if (light.kind == 1) {
+                PointAndNormal<R> lp = sample_on_shape(sc, sc.shapes.at(light.shape_id), v.pos, rng);
+                R d = length(lp.position - v.pos);
+                V3<R> light_dir = normalize(lp.position - v.pos);
+                R light_pdf = POWER ? get_light_pdf(sc, light_id, lp, v.pos) * (d * d) * sc.lights_power_pmf[light_id] /
+                                          (std::fmax(dot(-lp.normal, light_dir), R(0)))
+                                    : get_light_pdf(sc, light_id, lp, v.pos) * (d * d) /
+                                          (std::fmax(dot(-lp.normal, light_dir), R(0)) * nlights);
+                if (light_pdf <= 0) break;
+                R bsdf_pdf = get_bsdf_pdf(m, dir_in, light_dir, v, sc);
+                if (bsdf_pdf <= 0) break;
+                SampleRecord<R> rec{};
+                rec.dir_out = light_dir;
+                V3<R> FG = eval_bsdf(m, dir_in, rec, v, sc);
+                r = Ray<R>{v.pos, light_dir, sc.ray_eps, K<R>::inf()};
+                auto nv = scene_intersect(sc, r, pc ? &pc->closest : nullptr);
+                if (!nv) {
+                    if (POWER) radiance = radiance + throughput * sc.background;  // :327-331
+                    break;                                                         // uniform variant: undefined upstream
+                }
+                v = *nv;
+                if (POWER && v.area_light_id == -1) break;  // :333-335
+                throughput = throughput * (FG / (R(0.5) * light_pdf + R(0.5) * bsdf_pdf));
+            }
+        } else {
+            // sampling the BSDF
+            auto rec_ = sample_bsdf(m, dir_in, v, sc, rng);
+            if (!rec_) break;
+            SampleRecord<R> &rec = *rec_;
+            V3<R> FG = eval_bsdf(m, dir_in, rec, v, sc);
+            V3<R> dir_out = normalize(rec.dir_out);
+            R bsdf_pdf = rec.pdf;
+            if (bsdf_pdf <= R(0)) break;
+            r = Ray<R>{v.pos, dir_out, sc.ray_eps, K<R>::inf()};
+            auto nv = scene_intersect(sc, r, pc ? &pc->closest : nullptr);
+            R pdf = (sc.lights.empty() || is_specular) ? bsdf_pdf : R(0.5) * bsdf_pdf;
+            if (!nv) {
+                throughput = throughput * (FG / pdf);
+                radiance = radiance + throughput * sc.background;
+                break;
+            }
+            if (!is_specular && nv->area_light_id != -1) {
+                V3<R> light_pos = nv->pos;
+                R d = length(light_pos - v.pos);
+                V3<R> light_dir = normalize(light_pos - v.pos);
+                R lpdf = get_light_pdf(sc, nv->area_light_id, PointAndNormal<R>{nv->pos, nv->geo_normal}, v.pos) * (d * d);
+                R light_pdf = POWER ? lpdf * sc.lights_power_pmf[nv->area_light_id] / std::fmax(dot(-nv->geo_normal, light_dir), R(0))
+                                    : lpdf / (std::fmax(dot(-nv->geo_normal, light_dir), R(0)) * nlights);
+                if (light_pdf <= 0) break;
+                pdf += R(0.5) * light_pdf;
+            }
+            throughput = throughput * (FG / pdf);
+            v = *nv;
+        }
+    }
+    return radiance;
+}
+
+// TakeRenderOpts.integrator -> the reference function it selects
+enum Integrator { INT_PATH_MIS = 0, INT_RAW = 1, INT_ONE_SAMPLE = 2, INT_ONE_SAMPLE_POWER = 3 };
+template <class R, class Rng>
+V3<R> integrate(int integrator, const Scene<R> &sc, const Ray<R> &ray, Rng &rng, int max_depth, PathCounters *pc = nullptr) {
+    switch (integrator) {
+        case INT_RAW: return path_tracing_raw(sc, ray, rng, max_depth, pc);
+        case INT_ONE_SAMPLE: return path_tracing_one_sample<R, Rng, false>(sc, ray, rng, max_depth, pc);
+        case INT_ONE_SAMPLE_POWER: return path_tracing_one_sample<R, Rng, true>(sc, ray, rng, max_depth, pc);
+        default: return path_tracing(sc, ray, rng, max_depth, pc);
+    }
+}
+
 // ------------------------------------------------------------------ src/render.cpp:37-82
 template <class R> struct CameraBasis {
     V3<R> u, v, w, lookfrom;
@@ -991,7 +1164,7 @@ enum RngMode { RNG_MT_PER_TILE = 0, RNG_COUNTER = 1 };
 // atomic tile counter (same x-fastest tile order, one tile per grab).  out: H*W*3, image order (row 0 = top).
 template <class R>
 void render(const Scene<R> &sc, int spp, int max_depth, int rng_mode, uint64_t seed, int threads, R *out,
-            PathCounters *total = nullptr) {
+            PathCounters *total = nullptr, int integrator = 0) {
     const CameraBasis<R> cb = camera_basis<R>(sc.camera);
     const int W = cb.width, H = cb.height;
     constexpr int tile_size = 16;
@@ -1016,7 +1189,7 @@ void render(const Scene<R> &sc, int spp, int max_depth, int rng_mode, uint64_t s
                                 R ry = Draw<R, MtRng>::real(mt);
                                 R rx = Draw<R, MtRng>::real(mt);
                                 Ray<R> r = camera_ray(cb, x, y, rx, ry, sc.ray_eps);
-                                color = color + path_tracing(sc, r, mt, max_depth, pc);
+                                color = color + integrate(integrator, sc, r, mt, max_depth, pc);
                                 continue;
                             }
                         }
@@ -1024,7 +1197,7 @@ void render(const Scene<R> &sc, int spp, int max_depth, int rng_mode, uint64_t s
                         R ry = Draw<R, CounterRng>::real(cr);
                         R rx = Draw<R, CounterRng>::real(cr);
                         Ray<R> r = camera_ray(cb, x, y, rx, ry, sc.ray_eps);
-                        color = color + path_tracing(sc, r, cr, max_depth, pc);
+                        color = color + integrate(integrator, sc, r, cr, max_depth, pc);
                     }
                     V3<R> px = color / R(spp);
                     R *o = out + ((size_t)(H - y - 1) * W + x) * 3;  // img(x, height - y - 1)

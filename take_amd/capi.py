@@ -119,10 +119,11 @@ class Scene:
         except Exception:
             pass
 
-    def _opts(self, spp, max_depth, seed, ray_epsilon, strip_first, strip_stride, samples_per_batch):
+    def _opts(self, spp, max_depth, seed, ray_epsilon, strip_first, strip_stride, samples_per_batch, integrator=0):
         o = D.TakeRenderOpts()
         o.spp, o.max_depth, o.seed, o.ray_epsilon = int(spp), int(max_depth), int(seed), float(ray_epsilon)
         o.strip_first, o.strip_stride, o.samples_per_batch = int(strip_first), int(strip_stride), int(samples_per_batch)
+        o.integrator = int(integrator)
         return o
 
     def rows(self, strip_first=0, strip_stride=1):
@@ -132,20 +133,20 @@ class Scene:
         return np.array(out[:n], np.int32)
 
     def render(self, spp=None, max_depth=None, seed=0, ray_epsilon=0.0, strip_first=0, strip_stride=1,
-               samples_per_batch=0):
+               samples_per_batch=0, integrator=0):
         """-> (rows, W, 3) image rows owned by this strip set, top row first (host array)."""
         spp = self.sd.spp if spp is None else spp
         max_depth = self.sd.max_depth if max_depth is None else max_depth
-        o = self._opts(spp, max_depth, seed, ray_epsilon, strip_first, strip_stride, samples_per_batch)
+        o = self._opts(spp, max_depth, seed, ray_epsilon, strip_first, strip_stride, samples_per_batch, integrator)
         n = _check(lib().take_hip_render_rows(self.h, strip_first, strip_stride, None))
         out = np.zeros((n, self.sd.width, 3), self.dtype)
         _check(lib().take_hip_render(self.h, C.byref(o), out.ctypes.data))
         return out
 
     def render_device(self, d_ptr, spp, max_depth, seed=0, ray_epsilon=0.0, strip_first=0, strip_stride=1,
-                      samples_per_batch=0, stream=None):
+                      samples_per_batch=0, stream=None, integrator=0):
         """Render into device memory at `d_ptr` (e.g. a torch tensor's data_ptr()); blocks until done."""
-        o = self._opts(spp, max_depth, seed, ray_epsilon, strip_first, strip_stride, samples_per_batch)
+        o = self._opts(spp, max_depth, seed, ray_epsilon, strip_first, strip_stride, samples_per_batch, integrator)
         _check(lib().take_hip_render_device(self.h, C.byref(o), C.c_void_p(d_ptr), C.c_void_p(stream or 0)))
 
     def trace_closest(self, rays_abi):

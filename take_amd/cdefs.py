@@ -69,7 +69,11 @@ TAKE_BUILDER_DEVICE_LBVH = 1
 class TakeRenderOpts(C.Structure):
     _fields_ = [("spp", C.c_int32), ("max_depth", C.c_int32), ("seed", C.c_uint64), ("ray_epsilon", C.c_double),
                 ("strip_first", C.c_int32), ("strip_stride", C.c_int32), ("samples_per_batch", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("integrator", C.c_int32)]
+
+
+# TakeRenderOpts.integrator: the reference's integrators (src/integrator/path_tracing.h:5, :114, :161, :274)
+INTEGRATOR_PATH_MIS, INTEGRATOR_RAW, INTEGRATOR_ONE_SAMPLE_MIS, INTEGRATOR_ONE_SAMPLE_MIS_POWER = 0, 1, 2, 3
 
 
 class TakeRayF(C.Structure):

@@ -111,6 +111,7 @@ template <class R> struct SceneT {
     DevBuf<MaterialRec<R>> materials;
     DevBuf<ImageInfo> images;
     DevBuf<LightRec<R>> lights;
+    DevBuf<R> light_pmf, light_cdf;
     DevBuf<R> env_marginal, env_conditional;
     DevBuf<int32_t> env_guide_m, env_guide_c;
     DeviceScene<R> dev{};
@@ -137,6 +138,7 @@ template <class R> struct SceneT {
         nodes.release(), qnodes.release(), prims.release(), shapes.release(), meshes.release(), face_idx.release();
         normals.release(), uvs.release(), texels.release(), materials.release(), images.release(), lights.release();
         env_marginal.release(), env_conditional.release(), env_guide_m.release(), env_guide_c.release();
+        light_pmf.release(), light_cdf.release();
         state_r.release(), queue[0].release(), queue[1].release(), shadow_queue.release();
         sorted_queue.release(), sort_keys.release(), sort_hist.release(), sort_base.release(), accum.release(), out.release(), qwords.release(), counters.release(), spill.release();
     }
@@ -338,6 +340,8 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     HIP_TRY(sc.materials.upload(h.materials));
     HIP_TRY(sc.images.upload(h.images));
     HIP_TRY(sc.lights.upload(h.lights));
+    HIP_TRY(sc.light_pmf.upload(h.light_pmf));
+    HIP_TRY(sc.light_cdf.upload(h.light_cdf));
     HIP_TRY(sc.env_marginal.upload(h.env_marginal));
     HIP_TRY(sc.env_conditional.upload(h.env_conditional));
     HIP_TRY(sc.env_guide_m.upload(h.env_guide_m));
@@ -357,6 +361,8 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     d.materials = sc.materials.p;
     d.images = sc.images.p;
     d.lights = sc.lights.p;
+    d.light_pmf = sc.light_pmf.p;
+    d.light_cdf = sc.light_cdf.p;
     d.env.marginal = sc.env_marginal.p;
     d.env.conditional = sc.env_conditional.p;
     d.env.guide_m = sc.env_guide_m.p;
@@ -505,8 +511,12 @@ template <class R> struct ShadeArgs {
     hipStream_t stream;
 };
 template <class R, int TAG> void launch_shade_tag(const ShadeArgs<R> &a) {
-    hipLaunchKernelGGL((k_shade<R, TAG>), dim3(a.grid), dim3(BLOCK), 0, a.stream, a.dev, a.rp, a.st, a.queue, a.n_cur,
-                       a.tag_count, a.next_queue, a.n_next, a.shadow_queue, a.n_shadow, a.k, a.counters);
+    if (a.rp.integrator != 0)
+        hipLaunchKernelGGL((k_shade<R, TAG, true>), dim3(a.grid), dim3(BLOCK), 0, a.stream, a.dev, a.rp, a.st, a.queue, a.n_cur,
+                           a.tag_count, a.next_queue, a.n_next, a.shadow_queue, a.n_shadow, a.k, a.counters);
+    else
+        hipLaunchKernelGGL((k_shade<R, TAG, false>), dim3(a.grid), dim3(BLOCK), 0, a.stream, a.dev, a.rp, a.st, a.queue, a.n_cur,
+                           a.tag_count, a.next_queue, a.n_next, a.shadow_queue, a.n_shadow, a.k, a.counters);
 }
 template <class R> void launch_shade(int tag, const ShadeArgs<R> &a) {
     switch (tag) {
@@ -544,6 +554,9 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     const int W = sc.host.cam.width, H = sc.host.cam.height;
     if (o.spp <= 0) return fail(TAKE_E_INVALID, "spp must be positive");
     if (o.max_depth < -1) return fail(TAKE_E_INVALID, "max_depth must be >= -1");
+    if (o.integrator < 0 || o.integrator > 3) return fail(TAKE_E_INVALID, "unknown integrator");
+    if (o.integrator != 0 && sc.host.env.light >= 0)
+        return fail(TAKE_E_INVALID, "integrators 1..3 are the reference's own: they do not know the environment-map extension");
     const int stride = o.strip_stride > 0 ? o.strip_stride : 1;
     const int first = o.strip_first;
     if (first < 0 || first >= stride) return fail(TAKE_E_INVALID, "strip_first must be in [0, strip_stride)");
@@ -579,7 +592,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     RenderParams<R> rp{};
     rp.width = W, rp.height = H, rp.n_local_rows = n_rows, rp.npix = (int32_t)npix;
     rp.strip_first = first, rp.strip_stride = stride;
-    rp.spp = o.spp, rp.max_depth = o.max_depth, rp.seed = o.seed;
+    rp.spp = o.spp, rp.max_depth = o.max_depth, rp.seed = o.seed, rp.integrator = o.integrator;
     rp.ray_eps = o.ray_epsilon > 0 ? R(o.ray_epsilon) : (sizeof(R) == 8 ? R(1e-7) : R(1e-4));
 
     const bool timing = (ts->instrumentation & 1) != 0;
@@ -666,7 +679,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
             }
             tm.end();
             if (dump >= 0 && dump < slots) dump_slot(st, dump, "after shade", k, stream);
-            if (k <= o.max_depth) {
+            if (k <= o.max_depth && o.integrator == 0) {  // integrators 1..3 trace no shadow rays
                 tm.begin(TK_SHADOW);
                 launch_trace<R>(sc.group, true, counting, tgrid, stream, sc.dev, io_shadow, q + Q_N_SHADOW, 0,
                                 q + Q_HEAD_SHADOW, sc.counters.p, (int)C_RAYS_SHADOW, spill);

@@ -30,6 +30,7 @@ template <class R> struct HostScene {
     std::vector<MaterialRec<R>> materials;
     std::vector<ImageInfo> images;
     std::vector<LightRec<R>> lights;
+    std::vector<R> light_pmf, light_cdf;  // power-based light picking (integrator 3), see prepare_scene
     EnvMap<R> env{-1, 0, 0, 0, 0, {R(0), R(0), R(0)}, nullptr, nullptr, nullptr, nullptr};  // pointers: view() / the uploader
     std::vector<R> env_marginal, env_conditional;
     std::vector<int32_t> env_guide_m, env_guide_c;
@@ -58,6 +59,8 @@ template <class R> struct HostScene {
         d.images = images.data();
         d.texels = texels.data();
         d.lights = lights.data();
+        d.light_pmf = light_pmf.data();
+        d.light_cdf = light_cdf.data();
         d.env = env;
         d.env.marginal = env_marginal.data();
         d.env.conditional = env_conditional.data();
@@ -350,6 +353,36 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
                     o.v[3 * k + a] = R(m.positions[3 * (int64_t)idx[k] + a]);
                     o.n[3 * k + a] = R(m.normals[3 * (int64_t)idx[k] + a]);
                 }
+        }
+    }
+
+    // Power-based light picking (src/light.cpp:9-30).  The reference reads Scene::lights_power_pmf / _cdf but never
+    // fills them; filled here from its light_power(): luminance(intensity) * area * pi for an area light, 0 otherwise;
+    // pmf = power / total, cdf = running sum from 0 (n + 1 entries) — in R arithmetic, in light order (the recipe
+    // the golden `ptpow` tables were made with: the test harness applies it to the reference's own Scene).
+    {
+        std::vector<R> power;
+        R total = R(0);
+        for (const LightRec<R> &l : hs.lights) {
+            R p = R(0);
+            if (l.kind == 1) {
+                R area;
+                if (l.is_sphere) {
+                    area = R(4) * Const<R>::PI * l.v[3] * l.v[3];
+                } else {
+                    const Vec3<R> v0 = {l.v[0], l.v[1], l.v[2]}, v1 = {l.v[3], l.v[4], l.v[5]}, v2 = {l.v[6], l.v[7], l.v[8]};
+                    area = length(cross(v1 - v0, v2 - v0)) / R(2);
+                }
+                p = (l.intensity[0] * R(0.212671) + l.intensity[1] * R(0.715160) + l.intensity[2] * R(0.072169)) * area * Const<R>::PI;
+            }
+            power.push_back(p);
+            total += p;
+        }
+        hs.light_pmf.clear();
+        hs.light_cdf.assign(1, R(0));
+        for (R p : power) {
+            hs.light_pmf.push_back(p / total);
+            hs.light_cdf.push_back(hs.light_cdf.back() + p / total);
         }
     }
 

@@ -24,6 +24,7 @@ template <class R> struct RenderParams {
     int32_t s0;             // first sample index of this batch
     int32_t spb;            // samples per pixel in this batch
     int32_t max_depth;
+    int32_t integrator;     // TakeRenderOpts.integrator: 0 path_tracing, 1 raw, 2 one-sample MIS, 3 one-sample MIS by power
     uint64_t seed;
     R ray_eps;
 };
@@ -241,6 +242,154 @@ TK_HD uint32_t shade_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, c
     st.R_(S_LX, slot) = rad.x;
     st.R_(S_LY, slot) = rad.y;
     st.R_(S_LZ, slot) = rad.z;
+    return req;
+}
+
+// ---- the reference's other integrators (src/integrator/path_tracing.h:114-380; defined there, called by nothing):
+//   1  path_tracing_raw                    BSDF sampling only, emission on hit, no next-event estimation
+//   2  path_tracing_one_sample_MIS         per vertex EITHER a light sample OR a BSDF sample (coin flip), the one ray
+//                                          weighted by the mixture density; uniform light pick
+//   3  path_tracing_one_sample_MIS_power   the same with the light picked by power (light.cpp:9-30; the tables the
+//                                          parser leaves empty are filled from light_power(), tk_host_scene.h)
+// All three trace ONE closest-hit ray per vertex and no shadow rays: a round is trace -> shade.  An iteration of the
+// reference loop that does nothing (a PointLight was picked: `if (auto *l = get_if<DiffuseAreaLight>)` fails) is
+// run again inside the same shade call, so the loop index is carried in the path's flag word.
+constexpr int32_t FLAG_LIGHT_BRANCH = 2;  // the pending ray was aimed at a sampled light point
+constexpr int FLAG_ITER_SHIFT = 8;        // loop index `i` of the reference in bits 8..
+
+// src/light.cpp:9-17: std::upper_bound over the n + 1 entries of the power CDF, clamped to [0, n - 1]
+template <class R, class G> TK_HD int sample_light_by_power(const DeviceScene<R> &sc, G &rng) {
+    const R u = random_real<R>(rng);
+    const int size = sc.n_lights;
+    int lo = 0, hi = size + 1;  // first index in [0, size] whose entry is > u (size + 1 if none)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sc.light_cdf[mid] > u) hi = mid;
+        else lo = mid + 1;
+    }
+    const int off = lo - 1;
+    return off < 0 ? 0 : (off > size - 1 ? size - 1 : off);
+}
+
+template <class R, int TAG = TAG_ANY>
+TK_HD uint32_t shade_path_alt(const DeviceScene<R> &sc, const RenderParams<R> &rp, const PathState<R> &st, int64_t slot,
+                              int k) {
+    const bool raw = rp.integrator == 1, power = rp.integrator == 3;
+    const int32_t hit_prim = st.I_(S_HIT, slot);
+    const Vec3<R> ro{st.R_(S_OX, slot), st.R_(S_OY, slot), st.R_(S_OZ, slot)};
+    const Vec3<R> rd{st.R_(S_DX, slot), st.R_(S_DY, slot), st.R_(S_DZ, slot)};
+    Vec3<R> thr{st.R_(S_TX, slot), st.R_(S_TY, slot), st.R_(S_TZ, slot)};
+    Vec3<R> rad{st.R_(S_LX, slot), st.R_(S_LY, slot), st.R_(S_LZ, slot)};
+    const Vec3<R> bg = ld3(sc.background);
+    const R nlights = R(sc.n_lights);
+    const bool miss = (TAG == TAG_MISS) || hit_prim < 0;
+    Isect<R> v{};
+    if (!miss) make_isect(sc, ro, rd, hit_prim, st.R_(S_HT, slot), st.R_(S_HU, slot), st.R_(S_HV, slot), v);
+    const int32_t flags = st.I_(S_FLAGS, slot);
+    int iter = flags >> FLAG_ITER_SHIFT;
+    bool alive = true;
+    if (k == 0) {
+        iter = 0;
+        if (miss) rad = bg, alive = false;  // :117, :164, :277
+    } else {
+        // the ray of loop iteration `iter` has been traced: finish that iteration
+        const Vec3<R> FG{st.R_(S_FX, slot), st.R_(S_FY, slot), st.R_(S_FZ, slot)};
+        const R pdf = st.R_(S_PDF, slot);
+        if (raw) {
+            if (miss) rad = rad + thr * bg, alive = false;  // :148-152 (throughput was updated before the ray, :146)
+        } else if (flags & FLAG_LIGHT_BRANCH) {
+            if (miss) {
+                // :327-331 (power variant); the uniform variant dereferences the empty optional (:222) — a miss
+                // ends the path here, as in the oracle
+                if (power) rad = rad + thr * bg;
+                alive = false;
+            } else if (power && v.area_light == -1) {
+                alive = false;  // :333-335
+            } else {
+                thr = thr * (FG / pdf);  // pdf = 0.5 light_pdf + 0.5 bsdf_pdf, stored by the first half
+            }
+        } else {
+            const bool was_specular = (flags & FLAG_SPECULAR) != 0;
+            R p = (sc.n_lights == 0 || was_specular) ? pdf : R(0.5) * pdf;
+            if (miss) {
+                thr = thr * (FG / p);
+                rad = rad + thr * bg;
+                alive = false;
+            } else {
+                if (!was_specular && v.area_light != -1) {
+                    const LightRec<R> &l = sc.lights[v.area_light];
+                    const R d = length(v.pos - ro);
+                    const Vec3<R> light_dir = normalize(v.pos - ro);
+                    const R lpd = light_pdf_area(l, v.pos, ro) * (d * d);
+                    const R light_pdf = power ? lpd * sc.light_pmf[v.area_light] / tk_fmax(dot(-v.gn, light_dir), R(0))
+                                              : lpd / (tk_fmax(dot(-v.gn, light_dir), R(0)) * nlights);
+                    if (light_pdf <= R(0)) alive = false;
+                    else p = p + R(0.5) * light_pdf;
+                }
+                if (alive) thr = thr * (FG / p);
+            }
+        }
+        iter++;
+    }
+
+    uint32_t req = 0;
+    if (TAG != TAG_MISS && alive) {
+        Rng rng = path_rng(rp, slot, (uint32_t)st.I_(S_CTR, slot));
+        const Vec3<R> dir_in = -rd;
+        const MaterialRec<R> &m = sc.materials[v.material];
+        constexpr int MT = (TAG >= 0 && TAG < TAG_MISS) ? TAG : -1;
+        const int tag = MT >= 0 ? MT : m.tag;
+        const bool is_specular = (tag == 2 || tag == 1);
+        int32_t new_flags = 0;
+        for (; iter <= rp.max_depth; iter++) {
+            if (v.area_light != -1) {
+                const LightRec<R> &l = sc.lights[v.area_light];
+                if (l.kind == 1) {
+                    rad = rad + thr * ld3(l.intensity);
+                    break;
+                }
+                if (raw) continue;  // `else` of :121-127: an emitter id that is not a DiffuseAreaLight does nothing
+            }
+            if (!raw && sc.n_lights > 0 && !is_specular && random_real<R>(rng) <= R(0.5)) {
+                const int light_id = power ? sample_light_by_power(sc, rng) : (int)tk_floor(random_real<R>(rng) * nlights);
+                const LightRec<R> &l = sc.lights[light_id];
+                if (l.kind != 1) continue;  // a PointLight: the iteration does nothing
+                const LightSample<R> lp = sample_light_point(l, v.pos, rng);
+                const R d = length(lp.pos - v.pos);
+                const Vec3<R> light_dir = normalize(lp.pos - v.pos);
+                const R lpd = light_pdf_area(l, lp.pos, v.pos) * (d * d);
+                const R light_pdf = power ? lpd * sc.light_pmf[light_id] / tk_fmax(dot(-lp.n, light_dir), R(0))
+                                          : lpd / (tk_fmax(dot(-lp.n, light_dir), R(0)) * nlights);
+                if (light_pdf <= R(0)) break;
+                const R bp = bsdf_pdf<R, MT>(m, dir_in, light_dir, v);
+                if (bp <= R(0)) break;
+                const Vec3<R> FG = eval_bsdf<R, MT>(sc, m, dir_in, light_dir, R(0), v);
+                st.R_(S_DX, slot) = light_dir.x, st.R_(S_DY, slot) = light_dir.y, st.R_(S_DZ, slot) = light_dir.z;
+                st.R_(S_FX, slot) = FG.x, st.R_(S_FY, slot) = FG.y, st.R_(S_FZ, slot) = FG.z;
+                st.R_(S_PDF, slot) = R(0.5) * light_pdf + R(0.5) * bp;
+                new_flags = FLAG_LIGHT_BRANCH;
+                req = REQ_EXTEND;
+                break;
+            }
+            BsdfSample<R> rec;
+            if (!sample_bsdf<R, MT>(m, dir_in, v, rng, rec)) break;
+            const Vec3<R> FG = eval_bsdf<R, MT>(sc, m, dir_in, rec.dir_out, rec.pdf, v);
+            const Vec3<R> dir_out = normalize(rec.dir_out);
+            if (rec.pdf <= R(0)) break;
+            if (raw) thr = thr * (FG / rec.pdf);
+            st.R_(S_DX, slot) = dir_out.x, st.R_(S_DY, slot) = dir_out.y, st.R_(S_DZ, slot) = dir_out.z;
+            st.R_(S_FX, slot) = FG.x, st.R_(S_FY, slot) = FG.y, st.R_(S_FZ, slot) = FG.z;
+            st.R_(S_PDF, slot) = rec.pdf;
+            new_flags = is_specular ? FLAG_SPECULAR : 0;
+            req = REQ_EXTEND;
+            break;
+        }
+        st.R_(S_OX, slot) = v.pos.x, st.R_(S_OY, slot) = v.pos.y, st.R_(S_OZ, slot) = v.pos.z;
+        st.I_(S_CTR, slot) = (int32_t)rng.ctr;
+        st.I_(S_FLAGS, slot) = new_flags | (iter << FLAG_ITER_SHIFT);
+    }
+    st.R_(S_TX, slot) = thr.x, st.R_(S_TY, slot) = thr.y, st.R_(S_TZ, slot) = thr.z;
+    st.R_(S_LX, slot) = rad.x, st.R_(S_LY, slot) = rad.y, st.R_(S_LZ, slot) = rad.z;
     return req;
 }
 

@@ -54,7 +54,9 @@ k_generate(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, int32_t *queu
 // TAG: the kernel is instantiated per material tag (+ TAG_MISS).  With a sorted queue (`tag_count` != null) an
 // instance walks only its tag's segment [sum(tag_count[0..TAG)), +tag_count[TAG]); with an unsorted queue
 // (single-tag scenes) the one instance of the scene's tag walks the whole queue.
-template <class R, int TAG>
+// ALT: the reference's other integrators (shade_path_alt, tk_integrate.h; rp.integrator 1..3) — separate instances, so
+// that the default integrator's register allocation is untouched.
+template <class R, int TAG, bool ALT = false>
 __global__ void __launch_bounds__(BLOCK)
 k_shade(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, const int32_t *__restrict__ queue,
         const int32_t *__restrict__ n_ptr, const int32_t *__restrict__ tag_count, int32_t *next_queue,
@@ -73,7 +75,7 @@ k_shade(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, const int32_t *_
     int32_t slot = 0;
     if (i < n) {
         slot = queue[begin + i];
-        req = shade_path<R, TAG>(sc, rp, st, (int64_t)slot, k);
+        req = ALT ? shade_path_alt<R, TAG>(sc, rp, st, (int64_t)slot, k) : shade_path<R, TAG>(sc, rp, st, (int64_t)slot, k);
     }
     // Block-aggregated append to the two output queues: ballot + mbcnt inside each wave, wave counts combined in
     // LDS, ONE atomicAdd per block and queue.  (One atomic per wave on a single counter word was the limit of this

@@ -154,6 +154,8 @@ template <class R> struct DeviceScene {
     const ImageInfo *images;
     const R *texels;  // 3 per texel
     const LightRec<R> *lights;
+    const R *light_pmf;  // n_lights: power of each light / total (reference Scene::lights_power_pmf, scene.h:28)
+    const R *light_cdf;  // n_lights + 1: running sum from 0 (Scene::lights_power_cdf); integrator 3 only
     int32_t n_lights;
     int32_t n_shapes;
     R background[3];

@@ -34,10 +34,12 @@ def hostsim():
     return _HOSTSIM
 
 
-def render_opts(spp, max_depth, seed=0, ray_epsilon=0.0, strip_first=0, strip_stride=1, samples_per_batch=0):
+def render_opts(spp, max_depth, seed=0, ray_epsilon=0.0, strip_first=0, strip_stride=1, samples_per_batch=0,
+                integrator=0):
     o = D.TakeRenderOpts()
     o.spp, o.max_depth, o.seed, o.ray_epsilon = spp, max_depth, seed, ray_epsilon
     o.strip_first, o.strip_stride, o.samples_per_batch = strip_first, strip_stride, samples_per_batch
+    o.integrator = integrator
     return o
 
 
@@ -49,9 +51,9 @@ def n_local_rows(height, first, stride):
 
 
 def hostsim_render(sd, precision, spp, max_depth, seed=0, ray_epsilon=0.0, strip_first=0, strip_stride=1,
-                   samples_per_batch=0):
+                   samples_per_batch=0, integrator=0):
     desc, keep = sd.to_desc()
-    o = render_opts(spp, max_depth, seed, ray_epsilon, strip_first, strip_stride, samples_per_batch)
+    o = render_opts(spp, max_depth, seed, ray_epsilon, strip_first, strip_stride, samples_per_batch, integrator)
     rows = n_local_rows(sd.height, strip_first, strip_stride)
     out = np.zeros((rows, sd.width, 3), np.float64 if precision == 1 else np.float32)
     stats = (C.c_uint64 * 7)()

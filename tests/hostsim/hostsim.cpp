@@ -58,7 +58,7 @@ template <class R> int render_t(const TakeSceneDesc &desc, const TakeRenderOpts 
     RenderParams<R> rp{};
     rp.width = W, rp.height = H, rp.n_local_rows = n_rows, rp.npix = (int32_t)npix;
     rp.strip_first = o.strip_first, rp.strip_stride = stride;
-    rp.spp = o.spp, rp.max_depth = o.max_depth, rp.seed = o.seed;
+    rp.spp = o.spp, rp.max_depth = o.max_depth, rp.seed = o.seed, rp.integrator = o.integrator;
     rp.ray_eps = o.ray_epsilon > 0 ? R(o.ray_epsilon) : (sizeof(R) == 8 ? R(1e-7) : R(1e-4));
     const int spb = o.samples_per_batch > 0 ? std::min(o.samples_per_batch, o.spp) : o.spp;
     const int64_t slots = (int64_t)spb * npix;
@@ -99,7 +99,7 @@ template <class R> int render_t(const TakeSceneDesc &desc, const TakeRenderOpts 
             }
             if (dump >= 0 && dump < slots) dump_slot(st, dump, "after trace_closest", k);
             for (int32_t slot : q[cur]) {  // k_shade
-                uint32_t req = shade_path(sc, rp, st, (int64_t)slot, k);
+                uint32_t req = rp.integrator ? shade_path_alt(sc, rp, st, (int64_t)slot, k) : shade_path(sc, rp, st, (int64_t)slot, k);
                 if (req & REQ_EXTEND) q[next].push_back(slot);
                 if (req & REQ_SHADOW) shadow.push_back(slot);
             }

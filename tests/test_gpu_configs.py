@@ -1,0 +1,113 @@
+"""GPU: the BASELINE.json configurations at their own shapes (sizes the oracle cannot reach: size-independent
+properties, all bit-exact), plus a mixed-BSDF scene small enough for the oracle.
+
+  configs[2]  1M-triangle soup + env-map light, 1920x1080: determinism, 8-strip re-assembly == single-GPU image,
+              host-SAH tree == device-LBVH tree, batch invariance (what bench.py's default workload renders);
+  configs[3]  the same scene at 4096x4096, rendered as the 8 strip sets of an 8-GPU job and re-assembled: bit-exact
+              with the one-piece render (`bench.py --config 3` is this workload at 1024 spp);
+  configs[4]  mixed BSDFs (Diffuse, Plastic, Phong, BlinnPhong, three BlinnPhongMicrofacet exponents) on 100k+
+              triangles: f64 GPU vs the pinned oracle on a 20k soup (rounding level up to 6 bounces), f32 vs the
+              oracle's f32 twin, and at 150k triangles sort/strip/batch invariance of the material-sorted pipeline.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import rmse
+from take_amd import capi, scenes
+from take_amd import cdefs as D
+from take_amd.dist import strip_rows
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def soup1m_env():
+    sd = scenes.soup_scene(1_000_000, 1920, 1080, spp=1, envmap=(2048, 1024))
+    sc = capi.Scene(sd, precision=D.TAKE_PRECISION_F32)
+    yield sc
+    sc.close()
+
+
+def test_config2_envmap_fullsize_deterministic_and_sharded(soup1m_env):
+    sc = soup1m_env
+    full = sc.render(spp=2, max_depth=50, seed=12)
+    assert np.array_equal(full, sc.render(spp=2, max_depth=50, seed=12))
+    assert np.array_equal(full, sc.render(spp=2, max_depth=50, seed=12, samples_per_batch=1))
+    assert np.isfinite(full).all() and full.min() >= 0 and 0.01 < full.mean() < 50.0
+    img = np.zeros_like(full)
+    for r in range(8):
+        img[strip_rows(1080, r, 8)] = sc.render(spp=2, max_depth=50, seed=12, strip_first=r, strip_stride=8)
+    assert np.array_equal(img, full)
+    # the sky lights the scene: the same render without the map is darker
+    plain = capi.Scene(scenes.soup_scene(1_000_000, 1920, 1080, spp=1), precision=D.TAKE_PRECISION_F32)
+    try:
+        assert plain.render(spp=1, max_depth=50, seed=12).mean() < 0.9 * sc.render(spp=1, max_depth=50, seed=12).mean()
+    finally:
+        plain.close()
+
+
+def test_config2_envmap_fullsize_builder_independent(soup1m_env):
+    dev = capi.Scene(soup1m_env.sd, precision=D.TAKE_PRECISION_F32, builder=D.TAKE_BUILDER_DEVICE_LBVH)
+    try:
+        a = soup1m_env.render(spp=1, max_depth=50, seed=3)
+        b = dev.render(spp=1, max_depth=50, seed=3)
+        assert np.array_equal(a, b)
+    finally:
+        dev.close()
+
+
+def test_config3_4096_square_as_eight_strip_sets():
+    sd = scenes.soup_scene(1_000_000, 4096, 4096, spp=1, envmap=(2048, 1024))
+    sc = capi.Scene(sd, precision=D.TAKE_PRECISION_F32)
+    try:
+        full = sc.render(spp=1, max_depth=50, seed=21)
+        assert full.shape == (4096, 4096, 3) and np.isfinite(full).all()
+        img = np.zeros_like(full)
+        n_rows = 0
+        for r in range(8):
+            rows = strip_rows(4096, r, 8)
+            part = sc.render(spp=1, max_depth=50, seed=21, strip_first=r, strip_stride=8)
+            assert part.shape[0] == len(rows) == 512  # 1024 strips of 4 rows over 8 ranks: perfectly balanced
+            img[rows] = part
+            n_rows += len(rows)
+        assert n_rows == 4096 and np.array_equal(img, full)
+    finally:
+        sc.close()
+
+
+def test_config4_mixed_bsdfs_vs_oracle():
+    sd = scenes.soup_scene(20_000, 96, 96, spp=4, materials="mixed", envmap=(128, 64))
+    osc = oracle.OracleScene(sd, precision=1)
+    want = osc.render(4, 6, rng_mode=oracle.RNG_COUNTER, seed=9)
+    osc.close()
+    sc = capi.Scene(sd, precision=D.TAKE_PRECISION_F64)
+    got = sc.render(spp=4, max_depth=6, seed=9)
+    sc.close()
+    d = np.abs(got - want).max(axis=2)
+    assert np.median(d) < 1e-12 and (d < 1e-9).mean() >= 0.995, ((d < 1e-9).mean(), rmse(got, want))
+    o32 = oracle.OracleScene(sd, precision=0)
+    want32 = o32.render(4, 50, seed=9)
+    o32.close()
+    sc = capi.Scene(sd, precision=D.TAKE_PRECISION_F32)
+    got32 = sc.render(spp=4, max_depth=50, seed=9)
+    sc.close()
+    assert rmse(got32, want32) < 4e-3, rmse(got32, want32)
+    assert np.median(np.abs(got32.astype(np.float64) - want32)) < 1e-5
+
+
+def test_config4_mixed_bsdfs_150k_invariances():
+    sd = scenes.soup_scene(150_000, 640, 360, spp=2, materials="mixed", envmap=(256, 128))
+    sc = capi.Scene(sd, precision=D.TAKE_PRECISION_F32)
+    dev = capi.Scene(sd, precision=D.TAKE_PRECISION_F32, builder=D.TAKE_BUILDER_DEVICE_LBVH)
+    try:
+        a = sc.render(spp=2, max_depth=50, seed=4)
+        assert np.array_equal(a, sc.render(spp=2, max_depth=50, seed=4, samples_per_batch=1))
+        assert np.array_equal(a, dev.render(spp=2, max_depth=50, seed=4))
+        img = np.zeros_like(a)
+        for r in range(5):
+            img[strip_rows(360, r, 5)] = sc.render(spp=2, max_depth=50, seed=4, strip_first=r, strip_stride=5)
+        assert np.array_equal(img, a)
+    finally:
+        sc.close()
+        dev.close()
