@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAKE_HIP_ABI_VERSION 1
+#define TAKE_HIP_ABI_VERSION 2 /* 2: TakeSceneDesc.instances, TakeRenderOpts.integrator (was reserved) */
 
 /* error codes */
 #define TAKE_OK 0
@@ -116,6 +116,18 @@ typedef struct TakeLight {
     double position[3];
 } TakeLight;
 
+/* EXTENSION (BASELINE configs[4]: "10M-triangle instanced scene"; the reference has no instancing):
+ * one placement of a prototype mesh.  The mesh is NOT copied: the instance is a leaf of the top-level BVH that holds
+ * a transform, and a ray entering it is moved into the mesh's object space (two-level traversal).  The result is
+ * specified as that of the same geometry flattened to world space (xform applied to the vertices), to fp rounding.
+ * Instanced triangles are not emitters.  Their shape ids follow the ordinary shapes: n_shapes + (sum of the face
+ * counts of the preceding instances) + face.                                                               */
+typedef struct TakeInstance {
+    int32_t mesh_id;      /* index into TakeSceneDesc.meshes: the prototype (it need not appear in the shape arrays) */
+    int32_t material_id;  /* material of this placement; -1: the mesh's own */
+    double xform[12];     /* object -> world, 3x4 row-major affine: world = M[:, :3] * p + M[:, 3]; invertible */
+} TakeInstance;
+
 /* reference `Camera` (src/camera.h:5-11) */
 typedef struct TakeCamera {
     int32_t width, height;
@@ -146,6 +158,8 @@ typedef struct TakeSceneDesc {
     int32_t n_images;
     int32_t reserved;
     const TakeImage3 *images;
+    int64_t n_instances;            /* extension, see TakeInstance; 0 = none */
+    const TakeInstance *instances;
 } TakeSceneDesc;
 
 #define TAKE_PRECISION_F32 0

@@ -40,6 +40,10 @@ class TakeLight(C.Structure):
     _fields_ = [("kind", C.c_int32), ("shape_id", C.c_int32), ("intensity", c_double3), ("position", c_double3)]
 
 
+class TakeInstance(C.Structure):
+    _fields_ = [("mesh_id", C.c_int32), ("material_id", C.c_int32), ("xform", C.c_double * 12)]
+
+
 class TakeCamera(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("lookfrom", c_double3), ("lookat", c_double3),
                 ("up", c_double3), ("vfov", C.c_double)]
@@ -54,7 +58,8 @@ class TakeSceneDesc(C.Structure):
                 ("shape_face", C.POINTER(C.c_int32)), ("shape_area_light", C.POINTER(C.c_int32)),
                 ("n_lights", C.c_int32), ("n_materials", C.c_int32),
                 ("lights", C.POINTER(TakeLight)), ("materials", C.POINTER(TakeMaterial)),
-                ("n_images", C.c_int32), ("reserved", C.c_int32), ("images", C.POINTER(TakeImage3))]
+                ("n_images", C.c_int32), ("reserved", C.c_int32), ("images", C.POINTER(TakeImage3)),
+                ("n_instances", C.c_int64), ("instances", C.POINTER(TakeInstance))]
 
 
 class TakeBuildOpts(C.Structure):

@@ -112,6 +112,8 @@ template <class R> struct SceneT {
     DevBuf<ImageInfo> images;
     DevBuf<LightRec<R>> lights;
     DevBuf<R> light_pmf, light_cdf;
+    DevBuf<InstTrace<R>> inst_trace;
+    DevBuf<InstShade<R>> inst_shade;
     DevBuf<R> env_marginal, env_conditional;
     DevBuf<int32_t> env_guide_m, env_guide_c;
     DeviceScene<R> dev{};
@@ -132,13 +134,13 @@ template <class R> struct SceneT {
 
     size_t scene_bytes() const {
         return nodes.bytes() + qnodes.bytes() + prims.bytes() + shapes.bytes() + meshes.bytes() + face_idx.bytes() + normals.bytes() +
-               uvs.bytes() + texels.bytes() + materials.bytes() + images.bytes() + lights.bytes();
+               uvs.bytes() + texels.bytes() + materials.bytes() + images.bytes() + lights.bytes() + inst_trace.bytes() + inst_shade.bytes();
     }
     void release() {
         nodes.release(), qnodes.release(), prims.release(), shapes.release(), meshes.release(), face_idx.release();
         normals.release(), uvs.release(), texels.release(), materials.release(), images.release(), lights.release();
         env_marginal.release(), env_conditional.release(), env_guide_m.release(), env_guide_c.release();
-        light_pmf.release(), light_cdf.release();
+        light_pmf.release(), light_cdf.release(), inst_trace.release(), inst_shade.release();
         state_r.release(), queue[0].release(), queue[1].release(), shadow_queue.release();
         sorted_queue.release(), sort_keys.release(), sort_hist.release(), sort_base.release(), accum.release(), out.release(), qwords.release(), counters.release(), spill.release();
     }
@@ -292,13 +294,12 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     if (threads <= 0) threads = 1;
     int max_leaf = opts.max_leaf_size;
     if (max_leaf <= 0 && std::getenv("TAKE_HIP_MAX_LEAF")) max_leaf = std::atoi(std::getenv("TAKE_HIP_MAX_LEAF"));  // tuning knob
-    sc.group = 2;  // pair traversal: measured fastest on MI355X (profiles/)
-    if (const char *g = std::getenv("TAKE_HIP_GROUP")) sc.group = std::atoi(g);  // tuning knob: lanes per ray (1, 2, 4)
-    if (sc.group != 1 && sc.group != 4) sc.group = 2;
+    sc.group = 2;  // pair traversal: measured fastest on MI355X (round 1: quad 143.6, pair 121.5, one ray per lane 128.8 ms
+                   // of closest-hit time per 8.3 M samples); the other group sizes of the template are no longer instantiated
     const char *fmt_env = std::getenv("TAKE_HIP_NODES");
     const std::string fmt = fmt_env ? fmt_env : "";
     // device build: f32 scenes with enough primitives to make a tree; otherwise (and as its fall-back) the host SAH build
-    bool on_device = opts.builder == TAKE_BUILDER_DEVICE_LBVH && sizeof(R) == 4 && desc.n_shapes >= 8;
+    bool on_device = opts.builder == TAKE_BUILDER_DEVICE_LBVH && sizeof(R) == 4 && desc.n_shapes >= 8 && desc.n_instances == 0;
     std::string err = prepare_scene<R>(desc, max_leaf, threads, sc.host, !on_device);
     if (!err.empty()) return fail(TAKE_E_INVALID, err);
     HostScene<R> &h = sc.host;
@@ -342,6 +343,8 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     HIP_TRY(sc.lights.upload(h.lights));
     HIP_TRY(sc.light_pmf.upload(h.light_pmf));
     HIP_TRY(sc.light_cdf.upload(h.light_cdf));
+    HIP_TRY(sc.inst_trace.upload(h.inst_trace));
+    HIP_TRY(sc.inst_shade.upload(h.inst_shade));
     HIP_TRY(sc.env_marginal.upload(h.env_marginal));
     HIP_TRY(sc.env_conditional.upload(h.env_conditional));
     HIP_TRY(sc.env_guide_m.upload(h.env_guide_m));
@@ -361,6 +364,8 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     d.materials = sc.materials.p;
     d.images = sc.images.p;
     d.lights = sc.lights.p;
+    d.inst_trace = sc.inst_trace.p;
+    d.inst_shade = sc.inst_shade.p;
     d.light_pmf = sc.light_pmf.p;
     d.light_cdf = sc.light_cdf.p;
     d.env.marginal = sc.env_marginal.p;
@@ -373,17 +378,12 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     HIP_TRY(hipMemset(sc.counters.p, 0, sc.counters.bytes()));
     // persistent trace grid: resident blocks of the heaviest trace kernel x CUs
     int per_cu = 0;
-    int groups_per_block = 0, spill_levels = 0;
-    if (sc.group == 4) {
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 4, false, false, PathIo<R>>, TQ_BLOCK, 0));
-        groups_per_block = GroupGeom<4>::GROUPS, spill_levels = GroupGeom<4>::SPILL;
-    } else if (sc.group == 2) {
-        if (use_q) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>, true>, TQ_BLOCK, 0));
-        if (!use_q) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>>, TQ_BLOCK, 0));
-        groups_per_block = GroupGeom<2>::GROUPS, spill_levels = GroupGeom<2>::SPILL;
-    } else {
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 1, false, false, PathIo<R>>, TQ_BLOCK, 0));
-        groups_per_block = GroupGeom<1>::GROUPS, spill_levels = GroupGeom<1>::SPILL;
+    const int groups_per_block = GroupGeom<2>::GROUPS, spill_levels = GroupGeom<2>::SPILL;
+    if (use_q) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>, true>, TQ_BLOCK, 0));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>>, TQ_BLOCK, 0));
+    if (sc.inst_trace.n) {  // two-level scenes run the INST instances: size the persistent grid for them
+        if (use_q) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>, true, true>, TQ_BLOCK, 0));
+        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>, false, true>, TQ_BLOCK, 0));
     }
     per_cu = std::max(1, std::min(per_cu, 8));
     sc.trace_grid = ts->num_cus * per_cu;
@@ -471,29 +471,23 @@ template <class R, class Io>
 void launch_trace(int group, bool any, bool count, dim3 grid, hipStream_t stream, const DeviceScene<R> &dev, const Io &io,
                   const int32_t *n_ptr, int32_t n_direct, int32_t *head, unsigned long long *counters, int counter_word,
                   StackSpill spill) {
-#define TK_LAUNCH_Q(G, A, C, Q)                                                                                         \
-    hipLaunchKernelGGL((k_trace_group<R, G, A, C, Io, Q>), grid, dim3(TQ_BLOCK), 0, stream, dev, io, n_ptr, n_direct, head, \
+#define TK_LAUNCH(A, C, Q, I)                                                                                              \
+    hipLaunchKernelGGL((k_trace_group<R, 2, A, C, Io, Q, I>), grid, dim3(TQ_BLOCK), 0, stream, dev, io, n_ptr, n_direct, head, \
                        counters, counter_word, spill)
-#define TK_LAUNCH(G, A, C) TK_LAUNCH_Q(G, A, C, false)
-#define TK_LAUNCH_G(G)                     \
-    do {                                   \
-        if (any && count) TK_LAUNCH(G, true, true);        \
-        else if (any) TK_LAUNCH(G, true, false);           \
-        else if (count) TK_LAUNCH(G, false, true);         \
-        else TK_LAUNCH(G, false, false);                   \
+#define TK_LAUNCH_AC(Q, I)                          \
+    do {                                            \
+        if (any && count) TK_LAUNCH(true, true, Q, I);       \
+        else if (any) TK_LAUNCH(true, false, Q, I);          \
+        else if (count) TK_LAUNCH(false, true, Q, I);        \
+        else TK_LAUNCH(false, false, Q, I);                  \
     } while (0)
-    if (group == 2 && dev.qnodes) {  // compressed nodes (both precisions)
-        if (any && count) TK_LAUNCH_Q(2, true, true, true);
-        else if (any) TK_LAUNCH_Q(2, true, false, true);
-        else if (count) TK_LAUNCH_Q(2, false, true, true);
-        else TK_LAUNCH_Q(2, false, false, true);
-        return;
-    }
-    if (group == 4) TK_LAUNCH_G(4);
-    else if (group == 2) TK_LAUNCH_G(2);
-    else TK_LAUNCH_G(1);
-#undef TK_LAUNCH_G
-#undef TK_LAUNCH_Q
+    (void)group;  // pair kernel only
+    const bool q = dev.qnodes != nullptr, two_level = dev.inst_trace != nullptr;
+    if (q && two_level) TK_LAUNCH_AC(true, true);
+    else if (q) TK_LAUNCH_AC(true, false);
+    else if (two_level) TK_LAUNCH_AC(false, true);
+    else TK_LAUNCH_AC(false, false);
+#undef TK_LAUNCH_AC
 #undef TK_LAUNCH
 }
 
@@ -654,7 +648,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
                 // every wave of the sort gets >= 512 entries of the (bounded) queue: the one-block scan walks
                 // 13 x waves counters, which must not dominate small rounds (it was 40 % of a 256x256 render)
                 const int sort_grid = (int)std::max<int64_t>(1, std::min<int64_t>(wide_grid, (n_bound + 2047) / 2048));
-                hipLaunchKernelGGL((k_sort_count<R>), dim3(sort_grid), dim3(BLOCK), 0, stream, sc.dev.prims, st,
+                hipLaunchKernelGGL((k_sort_count<R>), dim3(sort_grid), dim3(BLOCK), 0, stream, sc.dev.prims, sc.dev.inst_shade, st,
                                    sc.queue[cur].p, n_cur, sc.sort_keys.p, sc.sort_hist.p);
                 hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(SORT_SCAN_THREADS), 0, stream, sc.sort_hist.p,
                                    sc.sort_base.p, tag_count, sort_grid * (BLOCK / WAVE));
@@ -752,7 +746,7 @@ int trace_impl(TakeScene *ts, const void *d_rays, int64_t n, void *d_hits, int32
     ts->events.reset();
     a = ts->events.get(), b = ts->events.get();
     HIP_TRY(hipEventRecord(a, stream));
-    const HookIo<R> io{sc.dev.prims, (const RayAoS<R> *)d_rays, (HitAoS<R> *)d_hits, d_occ};
+    const HookIo<R> io{sc.dev.prims, (const RayAoS<R> *)d_rays, (HitAoS<R> *)d_hits, d_occ, sc.dev.inst_shade};
     launch_trace<R>(sc.group, any, count, dim3(sc.trace_grid), stream, sc.dev, io, nullptr, (int32_t)n, q + Q_HEAD_CLOSEST,
                     sc.counters.p, -1, spill);
     HIP_TRY(hipEventRecord(b, stream));

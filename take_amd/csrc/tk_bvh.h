@@ -24,7 +24,7 @@ namespace tk {
 
 struct BuildPrim {
     double bmin[3], bmax[3];
-    int32_t id;
+    int32_t id;  // >= 0: index of the primitive record; < 0: instance -(1 + id) of a two-level scene (always a leaf of its own)
 };
 struct Bvh2Node {
     double bmin[3], bmax[3];
@@ -131,7 +131,10 @@ class Bvh2Builder {
                 if (cost < best_cost) best_cost = cost, best_axis = a, best_split = k;
             }
         }
-        if (cnt <= max_leaf_) {
+        bool has_instance = false;
+        if (cnt <= max_leaf_)
+            for (int i = lo; i < hi; i++) has_instance = has_instance || prims_[i].id < 0;
+        if (cnt <= max_leaf_ && !has_instance) {
             // make a leaf unless splitting is clearly cheaper (one node test + two smaller leaves)
             const double leaf_cost = b.half_area() * 1.0;
             const double split_cost = best_axis < 0 ? std::numeric_limits<double>::infinity()
@@ -193,14 +196,17 @@ struct WideBvhStats {
 
 // Collapse a BVH2 into Node4<R> records (breadth-first) and the leaf-ordered primitive permutation.
 // prim_order[i] = index into the BuildPrim array (post-build order) of the i-th primitive in leaf order.
+// `bprims` (the builder's primitive array, post-build order): needed only for two-level scenes, to turn the
+// single-primitive leaf of an instance into an instance word.
 template <class R>
 int32_t collapse_to_wide(const std::vector<Bvh2Node> &n2, int root, std::vector<Node4<R>> &out,
-                         std::vector<int32_t> &prim_order, WideBvhStats &stats) {
+                         std::vector<int32_t> &prim_order, WideBvhStats &stats, const std::vector<BuildPrim> *bprims = nullptr) {
     out.clear();
     prim_order.clear();
     stats = WideBvhStats{};
     if (root < 0) return CHILD_EMPTY;
     auto emit_leaf = [&](const Bvh2Node &n) {
+        if (bprims && n.count == 1 && (*bprims)[n.first].id < 0) return make_instance_word(-(*bprims)[n.first].id - 1);
         int32_t first = (int32_t)prim_order.size();
         for (int i = 0; i < n.count; i++) prim_order.push_back(n.first + i);
         return make_leaf(first, n.count);

@@ -4,6 +4,7 @@
 // parse_scene and the tile loop (src/render.cpp:37-50) plus build_bvh (src/scene.cpp:4-23).
 #pragma once
 
+#include <array>
 #include <cmath>
 #include <cstdlib>
 #include <string>
@@ -31,6 +32,9 @@ template <class R> struct HostScene {
     std::vector<ImageInfo> images;
     std::vector<LightRec<R>> lights;
     std::vector<R> light_pmf, light_cdf;  // power-based light picking (integrator 3), see prepare_scene
+    std::vector<InstTrace<R>> inst_trace;  // two-level scenes (TakeInstance): one record per placement
+    std::vector<InstShade<R>> inst_shade;
+    int64_t n_blas = 0, blas_nodes = 0, blas_prims = 0;  // stats: prototype trees and their total size
     EnvMap<R> env{-1, 0, 0, 0, 0, {R(0), R(0), R(0)}, nullptr, nullptr, nullptr, nullptr};  // pointers: view() / the uploader
     std::vector<R> env_marginal, env_conditional;
     std::vector<int32_t> env_guide_m, env_guide_c;
@@ -58,6 +62,9 @@ template <class R> struct HostScene {
         d.materials = materials.data();
         d.images = images.data();
         d.texels = texels.data();
+        d.inst_trace = inst_trace.empty() ? nullptr : inst_trace.data();
+        d.inst_shade = inst_shade.empty() ? nullptr : inst_shade.data();
+        d.n_instances = (int32_t)inst_trace.size();
         d.lights = lights.data();
         d.light_pmf = light_pmf.data();
         d.light_cdf = light_cdf.data();
@@ -153,6 +160,9 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
     if (d.n_shapes > 0 && (!d.shape_kind || !d.shape_ref || !d.shape_face || !d.shape_area_light))
         return "shape arrays missing";
     if (d.n_shapes >= (int64_t)1 << 28) return "too many shapes for the 4-wide leaf encoding (2^28)";
+    if (d.n_instances < 0 || (d.n_instances > 0 && !d.instances)) return "instance array missing";
+    if (d.n_instances >= (int64_t)1 << 28) return "too many instances";
+    if (d.n_instances > 0 && !build_bvh) return "instanced scenes are built by the host builder";
     make_camera<R>(d.camera, hs.cam);
     for (int a = 0; a < 3; a++) hs.background[a] = R(d.background[a]);
 
@@ -394,30 +404,192 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
         for (size_t k = 0; k < order.size(); k++) order[k] = (int32_t)k;
         hs.nodes.clear();
         hs.qnodes.clear();
+        hs.inst_trace.clear(), hs.inst_shade.clear();
+        hs.n_blas = hs.blas_nodes = hs.blas_prims = 0;
         hs.root_child = CHILD_EMPTY;
         hs.stats = WideBvhStats{};
         hs.stats.n_prims = (int64_t)order.size();
     } else {
         // default leaf size 2: on triangle soups the tighter leaf boxes save more primitive tests than the extra
         // interior nodes cost (1M soup: 48.5 node + 10.8 primitive tests per ray vs 42.6 + 42.6 with 4 per leaf)
-        Bvh2Builder builder(bp, max_leaf > 0 ? max_leaf : 2, threads);
+        const int leaf_size = max_leaf > 0 ? max_leaf : 2;
+        const char *fmt_env = std::getenv("TAKE_HIP_NODES");
+        const std::string fmt = fmt_env ? fmt_env : "";
+
+        // ---- two-level scenes (EXTENSION, TakeInstance): one tree per prototype mesh in object space ("BLAS"), their
+        // nodes and primitive records appended behind the top-level tree's; an instance enters the top-level build
+        // as one box and leaves it as an instance word.
+        struct Blas {
+            std::vector<Node4<R>> nodes;
+            std::vector<PrimRec<R>> prims;
+            int32_t root_child = CHILD_EMPTY;
+            double lo[3], hi[3];
+            int depth = 0;
+        };
+        std::vector<Blas> blas;
+        std::vector<int> blas_of_mesh(d.n_meshes, -1);
+        std::vector<int> inst_blas(d.n_instances, -1);
+        int max_blas_depth = 0;
+        int64_t shape_next = ns;
+        hs.inst_trace.assign(d.n_instances, InstTrace<R>{});
+        hs.inst_shade.assign(d.n_instances, InstShade<R>{});
+        for (int64_t i = 0; i < d.n_instances; i++) {
+            const TakeInstance &in = d.instances[i];
+            if (in.mesh_id < 0 || in.mesh_id >= d.n_meshes) return "instance " + std::to_string(i) + ": bad mesh id";
+            if (in.material_id < -1 || in.material_id >= d.n_materials) return "instance " + std::to_string(i) + ": bad material id";
+            const TakeMesh &m = d.meshes[in.mesh_id];
+            if (m.n_faces <= 0) return "instance " + std::to_string(i) + ": empty prototype mesh";
+            if (blas_of_mesh[in.mesh_id] < 0) {
+                blas_of_mesh[in.mesh_id] = (int)blas.size();
+                blas.emplace_back();
+                Blas &b = blas.back();
+                const MeshInfo &mi = hs.meshes[in.mesh_id];
+                std::vector<PrimRec<R>> brecs(m.n_faces);
+                std::vector<BuildPrim> bbp(m.n_faces);
+                for (int a = 0; a < 3; a++) b.lo[a] = std::numeric_limits<double>::infinity(), b.hi[a] = -b.lo[a];
+                for (int64_t f = 0; f < m.n_faces; f++) {
+                    PrimRec<R> &p = brecs[f];
+                    p = PrimRec<R>{};
+                    const int32_t *idx = m.indices + 3 * f;
+                    Vec3<R> v[3];
+                    for (int k = 0; k < 3; k++)
+                        v[k] = {R(m.positions[3 * (int64_t)idx[k]]), R(m.positions[3 * (int64_t)idx[k] + 1]),
+                                R(m.positions[3 * (int64_t)idx[k] + 2])};
+                    const Vec3<R> e1 = v[1] - v[0], e2 = v[2] - v[0];
+                    p.a[0] = v[0].x, p.a[1] = v[0].y, p.a[2] = v[0].z;
+                    p.a[3] = e1.x, p.a[4] = e1.y, p.a[5] = e1.z;
+                    p.a[6] = e2.x, p.a[7] = e2.y, p.a[8] = e2.z;
+                    p.shape_id = (int32_t)f;  // local: the shape id of a hit is InstShade::shape_base + this
+                    p.meta = PRIM_TRIANGLE | (hs.materials[m.material_id].tag << 8);
+                    p.material = m.material_id, p.area_light = -1, p.nidx = -1, p.mesh = in.mesh_id;
+                    if (mi.nbase >= 0 || mi.uvbase >= 0) p.nidx = mi.fbase + (int32_t)f, p.meta |= META_HAS_ATTR;
+                    for (int a = 0; a < 3; a++) {
+                        const double x0 = (double)(&v[0].x)[a], x1 = (double)(&v[1].x)[a], x2 = (double)(&v[2].x)[a];
+                        bbp[f].bmin[a] = std::min(x0, std::min(x1, x2));
+                        bbp[f].bmax[a] = std::max(x0, std::max(x1, x2));
+                        b.lo[a] = std::min(b.lo[a], bbp[f].bmin[a]), b.hi[a] = std::max(b.hi[a], bbp[f].bmax[a]);
+                    }
+                    bbp[f].id = (int32_t)f;
+                }
+                Bvh2Builder bb(bbp, leaf_size, threads);
+                const int broot = bb.build();
+                std::vector<int32_t> border;
+                WideBvhStats bst;
+                b.root_child = collapse_to_wide<R>(bb.nodes(), broot, b.nodes, border, bst);
+                b.depth = bst.depth;
+                b.prims.resize(border.size());
+                for (size_t k = 0; k < border.size(); k++) b.prims[k] = brecs[bbp[border[k]].id];
+                max_blas_depth = std::max(max_blas_depth, b.depth);
+            }
+            inst_blas[i] = blas_of_mesh[in.mesh_id];
+            const Blas &b = blas[inst_blas[i]];
+            // transforms: forward linear part for shading, inverse (in double) for the ray
+            const double *M = in.xform;
+            const double a00 = M[0], a01 = M[1], a02 = M[2], a10 = M[4], a11 = M[5], a12 = M[6], a20 = M[8], a21 = M[9], a22 = M[10];
+            const double det = a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
+            if (!(std::fabs(det) > 1e-300)) return "instance " + std::to_string(i) + ": singular transform";
+            const double inv[9] = {(a11 * a22 - a12 * a21) / det, (a02 * a21 - a01 * a22) / det, (a01 * a12 - a02 * a11) / det,
+                                   (a12 * a20 - a10 * a22) / det, (a00 * a22 - a02 * a20) / det, (a02 * a10 - a00 * a12) / det,
+                                   (a10 * a21 - a11 * a20) / det, (a01 * a20 - a00 * a21) / det, (a00 * a11 - a01 * a10) / det};
+            InstTrace<R> &it = hs.inst_trace[i];
+            for (int r = 0; r < 3; r++) {
+                for (int c = 0; c < 3; c++) it.inv[4 * r + c] = R(inv[3 * r + c]);
+                it.inv[4 * r + 3] = R(-(inv[3 * r] * M[3] + inv[3 * r + 1] * M[7] + inv[3 * r + 2] * M[11]));
+            }
+            InstShade<R> &is = hs.inst_shade[i];
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) is.fwd[3 * r + c] = R(M[4 * r + c]);
+            is.material = in.material_id >= 0 ? in.material_id : m.material_id;
+            is.tag = hs.materials[is.material].tag;
+            is.shape_base = (int32_t)shape_next;
+            shape_next += m.n_faces;
+            if (shape_next >= (int64_t)1 << 31) return "too many instanced faces for 32-bit shape ids";
+            // world box of the placement: the object box's corners under the transform, padded for the rounding of
+            // the transformed ray (the specification is the flattened geometry to fp rounding, see take_hip.h)
+            BuildPrim ib;
+            ib.id = -(int32_t)(i + 1);
+            for (int a = 0; a < 3; a++) ib.bmin[a] = std::numeric_limits<double>::infinity(), ib.bmax[a] = -ib.bmin[a];
+            double mag = 0;
+            for (int c8 = 0; c8 < 8; c8++) {
+                const double px = (c8 & 1) ? b.hi[0] : b.lo[0], py = (c8 & 2) ? b.hi[1] : b.lo[1], pz = (c8 & 4) ? b.hi[2] : b.lo[2];
+                for (int a = 0; a < 3; a++) {
+                    const double w = M[4 * a] * px + M[4 * a + 1] * py + M[4 * a + 2] * pz + M[4 * a + 3];
+                    ib.bmin[a] = std::min(ib.bmin[a], w), ib.bmax[a] = std::max(ib.bmax[a], w);
+                    mag = std::max(mag, std::fabs(w));
+                }
+            }
+            const double pad = mag * (sizeof(R) == 4 ? 4e-6 : 1e-13);
+            for (int a = 0; a < 3; a++) ib.bmin[a] -= pad, ib.bmax[a] += pad;
+            bp.push_back(ib);
+        }
+
+        Bvh2Builder builder(bp, leaf_size, threads);
         const int root = builder.build();
-        hs.root_child = collapse_to_wide<R>(builder.nodes(), root, hs.nodes, order, hs.stats);
+        hs.root_child = collapse_to_wide<R>(builder.nodes(), root, hs.nodes, order, hs.stats, d.n_instances > 0 ? &bp : nullptr);
+        int32_t top_prims = (int32_t)order.size();
+        // append the prototype trees: node indices and leaf ranges become global
+        const size_t top_nodes = hs.nodes.size();
+        std::vector<size_t> blas_node_base(blas.size()), blas_prim_base(blas.size());
+        {
+            size_t nb = top_nodes, pb = (size_t)top_prims;
+            for (size_t k = 0; k < blas.size(); k++) {
+                blas_node_base[k] = nb, blas_prim_base[k] = pb;
+                nb += blas[k].nodes.size(), pb += blas[k].prims.size();
+            }
+            if (pb >= ((size_t)1 << 28)) return "too many primitive records for the 4-wide leaf encoding (2^28)";
+            hs.nodes.reserve(nb);
+            for (size_t k = 0; k < blas.size(); k++) {
+                auto fix = [&](int32_t c) -> int32_t {
+                    if (c == CHILD_EMPTY) return c;
+                    if (c >= 0) return c + (int32_t)blas_node_base[k];
+                    return make_leaf(leaf_first(c) + (int32_t)blas_prim_base[k], leaf_count(c));
+                };
+                for (Node4<R> nd : blas[k].nodes) {
+                    for (int j = 0; j < 4; j++) nd.c[j].child = fix(nd.c[j].child);
+                    hs.nodes.push_back(nd);
+                }
+                blas[k].root_child = fix(blas[k].root_child);
+            }
+            hs.n_blas = (int64_t)blas.size(), hs.blas_nodes = (int64_t)(nb - top_nodes), hs.blas_prims = (int64_t)(pb - top_prims);
+        }
+        hs.stats.n_nodes = (int64_t)hs.nodes.size();
+        hs.stats.depth += max_blas_depth;  // the traversal stack holds both levels (+ one return marker)
+        for (int64_t i = 0; i < d.n_instances; i++) hs.inst_trace[i].root_child = blas[inst_blas[i]].root_child;
+
         hs.qnodes.clear();
         {
-            // Both precisions traverse the 64-byte compressed nodes unless the 16-bit scene grid is too coarse for the
+            // Both precisions traverse the 64-byte compressed nodes unless the 16-bit grid is too coarse for the
             // geometry (child boxes growing by more than 10 % in area on average: a scene mixing scales by >1e4), or on request
             // (TAKE_HIP_NODES=wide / =q16: A/B runs).  In f64 scenes only the box tests use them (conservative, so
-            // exactness is not at stake); hits are decided by the double-precision primitive tests.
-            const char *fmt = std::getenv("TAKE_HIP_NODES");
-            const std::string f = fmt ? fmt : "";
-            if (f != "wide" && !hs.nodes.empty()) {
-                hs.q_inflation = quantise_nodes<R>(hs.nodes, hs.qnodes, hs.grid_lo, hs.grid_step);
-                if (hs.q_inflation > 1.10 && f != "q16") hs.qnodes.clear();
+            // exactness is not at stake); hits are decided by the double-precision primitive tests.  Every tree of a
+            // two-level scene has its own grid (the top-level one is the scene's, a prototype's is in its InstTrace).
+            if (fmt != "wide" && !hs.nodes.empty()) {
+                std::vector<Node4<R>> part(hs.nodes.begin(), hs.nodes.begin() + top_nodes);
+                std::vector<QNode4> q;
+                hs.q_inflation = top_nodes ? quantise_nodes<R>(part, q, hs.grid_lo, hs.grid_step) : 1.0;
+                hs.qnodes = q;
+                std::vector<std::array<float, 6>> grids(blas.size());
+                for (size_t k = 0; k < blas.size(); k++) {
+                    part.assign(hs.nodes.begin() + blas_node_base[k], hs.nodes.begin() + blas_node_base[k] + blas[k].nodes.size());
+                    float glo[3], gst[3];
+                    const double infl = part.empty() ? 1.0 : quantise_nodes<R>(part, q, glo, gst);
+                    if (part.empty()) q.clear(), glo[0] = glo[1] = glo[2] = 0, gst[0] = gst[1] = gst[2] = 1;
+                    hs.q_inflation = std::max(hs.q_inflation, infl);
+                    hs.qnodes.insert(hs.qnodes.end(), q.begin(), q.end());
+                    grids[k] = {glo[0], glo[1], glo[2], gst[0], gst[1], gst[2]};
+                }
+                for (int64_t i = 0; i < d.n_instances; i++)
+                    for (int a = 0; a < 3; a++)
+                        hs.inst_trace[i].grid_lo[a] = grids[inst_blas[i]][a], hs.inst_trace[i].grid_step[a] = grids[inst_blas[i]][3 + a];
+                if (hs.q_inflation > 1.10 && fmt != "q16") hs.qnodes.clear();
             }
         }
+        // primitive records: the top-level tree's in leaf order, then each prototype's
+        hs.prims.resize((size_t)top_prims + (size_t)hs.blas_prims);
+        for (size_t k = 0; k < blas.size(); k++)
+            std::copy(blas[k].prims.begin(), blas[k].prims.end(), hs.prims.begin() + blas_prim_base[k]);
     }
-    hs.prims.resize(order.size());
+    if (hs.prims.size() < order.size()) hs.prims.resize(order.size());  // (two-level scenes: the prototypes' records follow)
     for_chunks((int64_t)order.size(), threads, [&](int64_t k_begin, int64_t k_end) -> std::string {
     for (int64_t k = k_begin; k < k_end; k++) {
         hs.prims[k] = recs[bp[order[k]].id];
@@ -434,7 +606,7 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
     }
     return "";
     });
-    if (3 * hs.stats.depth + 1 > MAX_STACK_ENTRIES) return "BVH too deep for the traversal stack";
+    if (3 * hs.stats.depth + 2 > MAX_STACK_ENTRIES) return "BVH too deep for the traversal stack";
     return "";
 }
 

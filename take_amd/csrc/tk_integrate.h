@@ -100,7 +100,8 @@ TK_HD uint32_t shade_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, c
     const bool miss = (TAG == TAG_MISS) || hit_prim < 0;
     Isect<R> v{};
     bool alive = !miss;
-    if (!miss) make_isect(sc, ro, rd, hit_prim, st.R_(S_HT, slot), st.R_(S_HU, slot), st.R_(S_HV, slot), v);
+    if (!miss) make_isect(sc, ro, rd, hit_prim, st.R_(S_HT, slot), st.R_(S_HU, slot), st.R_(S_HV, slot), v,
+                            sc.inst_shade ? st.I_(S_INST, slot) : -1);
 
     if (k == 0) {
         // src/integrator/path_tracing.h:7-18
@@ -284,7 +285,8 @@ TK_HD uint32_t shade_path_alt(const DeviceScene<R> &sc, const RenderParams<R> &r
     const R nlights = R(sc.n_lights);
     const bool miss = (TAG == TAG_MISS) || hit_prim < 0;
     Isect<R> v{};
-    if (!miss) make_isect(sc, ro, rd, hit_prim, st.R_(S_HT, slot), st.R_(S_HU, slot), st.R_(S_HV, slot), v);
+    if (!miss) make_isect(sc, ro, rd, hit_prim, st.R_(S_HT, slot), st.R_(S_HU, slot), st.R_(S_HV, slot), v,
+                            sc.inst_shade ? st.I_(S_INST, slot) : -1);
     const int32_t flags = st.I_(S_FLAGS, slot);
     int iter = flags >> FLAG_ITER_SHIFT;
     bool alive = true;

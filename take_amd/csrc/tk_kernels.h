@@ -114,9 +114,15 @@ k_shade(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, const int32_t *_
 // The sorted order is deterministic (ranges and ranks do not depend on timing).
 constexpr int N_SORT_KEYS = TAKE_MAT_COUNT + 1;
 constexpr int SORT_SCAN_THREADS = 1024;
-template <class R> __device__ __forceinline__ int sort_key(const PrimRec<R> *__restrict__ prims, const PathState<R> &st, int32_t slot) {
+template <class R> __device__ __forceinline__ int sort_key(const PrimRec<R> *__restrict__ prims, const InstShade<R> *__restrict__ inst_shade,
+                                                       const PathState<R> &st, int32_t slot) {
     const int32_t prim = st.I_(S_HIT, slot);
-    return prim < 0 ? N_SORT_KEYS - 1 : ((prims[prim].meta >> 8) & 0xff);
+    if (prim < 0) return N_SORT_KEYS - 1;
+    if (inst_shade) {  // two-level scenes: the material of a placement overrides the prototype's
+        const int32_t inst = st.I_(S_INST, slot);
+        if (inst >= 0) return inst_shade[inst].tag;
+    }
+    return (prims[prim].meta >> 8) & 0xff;
 }
 // range of queue entries owned by global wave `w` of `n_waves`: multiples of 64, contiguous, covering [0, n)
 __device__ __forceinline__ void sort_range(int32_t n, int32_t w, int32_t n_waves, int32_t &begin, int32_t &end) {
@@ -127,8 +133,8 @@ __device__ __forceinline__ void sort_range(int32_t n, int32_t w, int32_t n_waves
 }
 template <class R>
 __global__ void __launch_bounds__(BLOCK)
-k_sort_count(const PrimRec<R> *__restrict__ prims, PathState<R> st, const int32_t *__restrict__ queue,
-             const int32_t *__restrict__ n_ptr, uint8_t *keys, int32_t *hist) {
+k_sort_count(const PrimRec<R> *__restrict__ prims, const InstShade<R> *__restrict__ inst_shade, PathState<R> st,
+             const int32_t *__restrict__ queue, const int32_t *__restrict__ n_ptr, uint8_t *keys, int32_t *hist) {
     const int32_t n = *n_ptr, n_waves = gridDim.x * (BLOCK / WAVE);
     const int32_t w = blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
     int32_t begin, end;
@@ -138,7 +144,7 @@ k_sort_count(const PrimRec<R> *__restrict__ prims, PathState<R> st, const int32_
     for (int t = 0; t < N_SORT_KEYS; t++) cnt[t] = 0;
     for (int32_t i = begin + lane_id(); i < end + lane_id(); i += WAVE) {  // uniform trip count
         const bool valid = i < end;
-        const int key = valid ? sort_key(prims, st, queue[i]) : -1;
+        const int key = valid ? sort_key(prims, inst_shade, st, queue[i]) : -1;
         if (valid) keys[i] = (uint8_t)key;
 #pragma unroll
         for (int t = 0; t < N_SORT_KEYS; t++) cnt[t] += (int32_t)__popcll(__ballot(key == t));

@@ -20,10 +20,16 @@ constexpr int32_t CHILD_EMPTY = (int32_t)0x80000000;
 constexpr int MAX_LEAF = 4;
 constexpr int MAX_STACK_ENTRIES = 96;  // deepest traversal stack the trace kernels provide (LDS levels + spill area): 3 per tree level + 1
 
-// child word: >= 0 interior node index; < 0 (and != CHILD_EMPTY) leaf: -(1 + first*4 + (count-1))
+// child word: >= 0 interior node index; < 0 (and != CHILD_EMPTY) leaf: -(1 + first*4 + (count-1)), first < 2^28, i.e.
+// leaf words lie in [-2^30, -1]; the words between CHILD_EMPTY and -2^30 are instance references (two-level scenes:
+// the leaf of the top-level tree that holds instance `id`): CHILD_EMPTY + 1 + id.
 TK_HD int32_t make_leaf(int32_t first, int32_t count) { return -(1 + first * MAX_LEAF + (count - 1)); }
 TK_HD int32_t leaf_first(int32_t c) { return (-c - 1) / MAX_LEAF; }
 TK_HD int32_t leaf_count(int32_t c) { return ((-c - 1) % MAX_LEAF) + 1; }
+constexpr int32_t INSTANCE_WORD_END = -(1 << 30);  // instance words are < this (and > CHILD_EMPTY)
+TK_HD int32_t make_instance_word(int32_t id) { return (int32_t)(0x80000001u + (uint32_t)id); }
+TK_HD bool is_instance_word(int32_t c) { return c < INSTANCE_WORD_END && c != CHILD_EMPTY; }
+TK_HD int32_t instance_of_word(int32_t c) { return (int32_t)((uint32_t)c - 0x80000001u); }
 
 // One child slot of a wide node: box + child word.  32 B in f32: the four lanes of a traversal quad each load one
 // slot (2 x dwordx4), i.e. one wave instruction reads whole 128-B lines, 4 lanes per line.
@@ -131,6 +137,26 @@ template <class R> struct LightRec {
     R n[9];  // triangle: vertex normals n0 n1 n2
 };
 
+// ---- instancing (EXTENSION, TakeInstance): a placement of a prototype mesh = one leaf of the top-level tree.
+// What the trace kernel reads when a ray enters the instance: world -> object transform, the root of the mesh's own
+// BVH (node indices and leaf ranges are global: all trees share `nodes` / `prims`) and, for compressed nodes, that
+// tree's quantisation grid.
+template <class R> struct alignas(16) InstTrace {
+    R inv[12];          // world -> object, 3x4 row-major (t along a ray is the same number in both spaces)
+    float grid_lo[3], grid_step[3];
+    int32_t root_child;
+    int32_t pad;
+};
+// What the shade kernel reads for a hit inside an instance: object -> world linear part (edges of the hit triangle),
+// the transposed inverse for normals comes from InstTrace::inv; the material of the placement.
+template <class R> struct alignas(16) InstShade {
+    R fwd[9];           // linear part of object -> world, row-major
+    int32_t material;   // material of this placement (already resolved: never -1)
+    int32_t tag;        // its tag (the material sort reads it)
+    int32_t shape_base; // shape id of the instance's face 0
+    int32_t pad;
+};
+
 template <class R> struct CameraRec {
     R u[3], v[3], w[3], lookfrom[3];
     R viewport_width, viewport_height;
@@ -153,6 +179,9 @@ template <class R> struct DeviceScene {
     const MaterialRec<R> *materials;
     const ImageInfo *images;
     const R *texels;  // 3 per texel
+    const InstTrace<R> *inst_trace;  // two-level scenes (TakeInstance), else null
+    const InstShade<R> *inst_shade;
+    int32_t n_instances;
     const LightRec<R> *lights;
     const R *light_pmf;  // n_lights: power of each light / total (reference Scene::lights_power_pmf, scene.h:28)
     const R *light_cdf;  // n_lights + 1: running sum from 0 (Scene::lights_power_cdf); integrator 3 only
@@ -181,8 +210,9 @@ enum StateR {
     S_CX, S_CY, S_CZ,          // throughput * C1: added to radiance if the shadow ray is unoccluded
     S_NUM_R = 29
 };
-enum StateI { S_HIT = 9, S_CTR = 10, S_FLAGS = 11, S_NUM_I = 3 };  // integer words of the same record
+enum StateI { S_HIT = 9, S_CTR = 10, S_FLAGS = 11, S_INST = 29, S_NUM_I = 4 };  // integer words of the same record
 // S_HIT: index of the hit primitive (leaf order), -1 = the extend ray missed
+// S_INST: instance the hit primitive was reached through (two-level scenes only; -1 = none)
 constexpr int PATH_REC = 32;
 constexpr int32_t FLAG_SPECULAR = 1;
 

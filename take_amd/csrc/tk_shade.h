@@ -24,8 +24,13 @@ template <class R> TK_HD Vec3<R> ld3(const R *p) { return {p[0], p[1], p[2]}; }
 // Rebuild the full intersection record from (primitive, t, u, v) and the ray: src/shape.cpp:30-40 (sphere),
 // :80-108 (triangle).  `prim` indexes the leaf-ordered primitive records (the closest-hit kernel reports it);
 // vertex attributes come from the shading-side arrays through the shape id stored in the record.
+// `inst` >= 0 (two-level scenes, EXTENSION): the primitive record is in the object space of its prototype; the
+// placement's transform takes the triangle's edges (geometric normal) and the interpolated vertex normal to world
+// space, exactly what flattening the instance would have produced up to rounding.  pos = ro + rd * t needs nothing:
+// t is the same number in both spaces.
 template <class R>
-TK_HD void make_isect(const DeviceScene<R> &sc, Vec3<R> ro, Vec3<R> rd, int32_t prim, R t, R u, R v, Isect<R> &out) {
+TK_HD void make_isect(const DeviceScene<R> &sc, Vec3<R> ro, Vec3<R> rd, int32_t prim, R t, R u, R v, Isect<R> &out,
+                      int32_t inst = -1) {
     const PrimRec<R> &p = sc.prims[prim];
     out.material = p.material;
     out.area_light = p.area_light;
@@ -41,6 +46,13 @@ TK_HD void make_isect(const DeviceScene<R> &sc, Vec3<R> ro, Vec3<R> rd, int32_t 
         return;
     }
     Vec3<R> e1{p.a[3], p.a[4], p.a[5]}, e2{p.a[6], p.a[7], p.a[8]};
+    if (inst >= 0) {
+        const InstShade<R> &is = sc.inst_shade[inst];
+        const R *f = is.fwd;
+        e1 = {f[0] * e1.x + f[1] * e1.y + f[2] * e1.z, f[3] * e1.x + f[4] * e1.y + f[5] * e1.z, f[6] * e1.x + f[7] * e1.y + f[8] * e1.z};
+        e2 = {f[0] * e2.x + f[1] * e2.y + f[2] * e2.z, f[3] * e2.x + f[4] * e2.y + f[5] * e2.z, f[6] * e2.x + f[7] * e2.y + f[8] * e2.z};
+        out.material = is.material;
+    }
     Vec3<R> gn = normalize(cross(e1, e2));
     gn = dot(rd, gn) < R(0) ? gn : -gn;
     out.gn = gn;
@@ -58,7 +70,12 @@ TK_HD void make_isect(const DeviceScene<R> &sc, Vec3<R> ro, Vec3<R> rd, int32_t 
     if (mi.nbase >= 0) {
         const R *nn = sc.normals + 3 * (int64_t)mi.nbase;
         Vec3<R> n0 = ld3(nn + 3 * i0), n1 = ld3(nn + 3 * i1), n2 = ld3(nn + 3 * i2);
-        out.sn = normalize((R(1) - u - v) * n0 + u * n1 + v * n2);
+        Vec3<R> sn = (R(1) - u - v) * n0 + u * n1 + v * n2;
+        if (inst >= 0) {  // normals transform with the transposed inverse: n_w = (L^-1)^T n
+            const R *b = sc.inst_trace[inst].inv;
+            sn = {b[0] * sn.x + b[4] * sn.y + b[8] * sn.z, b[1] * sn.x + b[5] * sn.y + b[9] * sn.z, b[2] * sn.x + b[6] * sn.y + b[10] * sn.z};
+        }
+        out.sn = normalize(sn);
     }
 }
 

@@ -89,6 +89,10 @@ template <class R> struct PathIo {  // the render loop: rays in the path state, 
     template <bool SHADOW> __device__ __forceinline__ void load(int32_t i, RayT<R> &ray, int32_t &tag) const {
         const int64_t slot = queue[i];
         tag = (int32_t)slot;
+        reload<SHADOW>(slot, ray);
+    }
+    // the ray of path `slot` again (two-level scenes: a ray that leaves an instance gets its world-space form back)
+    template <bool SHADOW> __device__ __forceinline__ void reload(int64_t slot, RayT<R> &ray) const {
         if (!SHADOW)
             ray = make_ray(st.R_(S_OX, slot), st.R_(S_OY, slot), st.R_(S_OZ, slot), st.R_(S_DX, slot), st.R_(S_DY, slot),
                            st.R_(S_DZ, slot), eps, Const<R>::inf());
@@ -104,6 +108,7 @@ template <class R> struct PathIo {  // the render loop: rays in the path state, 
         st.R_(S_HU, slot) = u;
         st.R_(S_HV, slot) = v;
     }
+    __device__ __forceinline__ void store_instance(int64_t slot, int32_t inst) const { st.I_(S_INST, slot) = inst; }
     __device__ __forceinline__ void store_occlusion(int64_t slot, bool occluded) const {
         if (!occluded) {  // the NEE term of this iteration reaches the light (path_tracing.h:53-58)
             st.R_(S_LX, slot) = st.R_(S_LX, slot) + st.R_(S_CX, slot);
@@ -129,10 +134,18 @@ template <class R> struct HookIo {  // the C-ABI trace hooks: AoS rays in, hit r
     const RayAoS<R> *rays;
     HitAoS<R> *hits;
     int32_t *occluded;
+    const InstShade<R> *inst_shade;  // two-level scenes: shape id of an instanced hit = shape_base + local face
     template <bool SHADOW> __device__ __forceinline__ void load(int32_t i, RayT<R> &ray, int32_t &tag) const {
-        const RayAoS<R> q = rays[i];
         tag = i;
+        reload<SHADOW>(i, ray);
+    }
+    template <bool SHADOW> __device__ __forceinline__ void reload(int64_t i, RayT<R> &ray) const {
+        const RayAoS<R> q = rays[i];
         ray = make_ray(q.org[0], q.org[1], q.org[2], q.dir[0], q.dir[1], q.dir[2], q.tmin, q.tmax);
+    }
+    // called after store_hit by the same lane
+    __device__ __forceinline__ void store_instance(int64_t i, int32_t inst) const {
+        if (inst >= 0 && hits[i].shape_id >= 0) hits[i].shape_id += inst_shade[inst].shape_base;
     }
     __device__ __forceinline__ void store_hit(int64_t i, int32_t prim, R t, R u, R v) const {
         HitAoS<R> h{};
@@ -169,8 +182,12 @@ template <int G> __device__ __forceinline__ int group_max_i(int v) {
 }
 
 // QN: traverse the 64-byte compressed nodes (sc.qnodes; pairs only) instead of the full-width ones.
-template <class R, int G, bool ANY_HIT, bool COUNT, class Io, bool QN = false>
-__global__ void __launch_bounds__(TQ_BLOCK, sizeof(R) == 8 ? 4 : TQ_MIN_WAVES)  // f64 (parity mode): room for the wider state
+// INST: two-level scenes (TakeInstance).  A leaf of the top-level tree may be an instance word: the ray is moved into
+// the prototype's object space (t is the same number in both spaces), a return marker goes on the stack, traversal
+// continues at the prototype's root; when the marker is popped the ray gets its world-space form back.  A separate
+// instance of the kernel, so that one-level scenes pay nothing.
+template <class R, int G, bool ANY_HIT, bool COUNT, class Io, bool QN = false, bool INST = false>
+__global__ void __launch_bounds__(TQ_BLOCK, sizeof(R) == 8 ? (INST ? 3 : 4) : (INST ? TQ_MIN_WAVES - 1 : TQ_MIN_WAVES))  // f64, two-level: room for the wider state
 k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_t n_direct, int32_t *head,
               unsigned long long *counters, int counter_word, StackSpill spill) {
     using GG = GroupGeom<G>;
@@ -208,6 +225,10 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
     // per-lane best candidate (differs between the lanes of a group)
     R my_t = Const<R>::inf(), my_u = R(0), my_v = R(0);
     int32_t my_prim = -1;
+    int32_t inst = -1, my_inst = -1;  // INST: instance the ray is inside of / the candidate was found in
+    Vec3<R> w_o{}, w_d{};             // INST: the world-space ray while the lanes are inside an instance
+    QRay w_qr{};
+    R w_idx = R(0), w_idy = R(0), w_idz = R(0);
     uint32_t cnt_nodes = 0, cnt_prims = 0, cnt_leaves = 0, cnt_wnode = 0, cnt_wleaf = 0, cnt_wait = 0, cnt_idle = 0;
 
     // The trace kernels are bound by VALU issue (profiles/): stack addressing uses 24-bit multiplies
@@ -229,6 +250,13 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
             --sp;
             const tq_entry e = (sp < GG::LEVELS) ? *lds_level(sp) : tq_spill_load(spill_at(sp));
             cur = (int32_t)(uint32_t)e;
+            if (INST && cur == CHILD_EMPTY) {  // the return marker of an instance: back to world space
+                ray.o = w_o, ray.d = w_d;
+                if constexpr (QN) qr = w_qr;
+                else idx = w_idx, idy = w_idy, idz = w_idz;
+                inst = -1;
+                continue;
+            }
             if (ANY_HIT) return false;  // the limit of a shadow ray never shrinks: nothing to cull
             const float key = __uint_as_float((uint32_t)(e >> 32) & ~3u);
             if ((R)key <= tbest) return false;
@@ -268,9 +296,13 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                 any = any || pany;
             }
             if (!any) {
-                if (gl == 0) io.store_hit(tag, -1, ray.tmax, R(0), R(0));
+                if (gl == 0) {
+                    io.store_hit(tag, -1, ray.tmax, R(0), R(0));
+                    if (INST) io.store_instance(tag, -1);
+                }
             } else if (mine) {
                 io.store_hit(tag, my_prim, my_t, my_u, my_v);
+                if (INST) io.store_instance(tag, my_inst);
             }
         }
         cur = CHILD_EMPTY;
@@ -311,6 +343,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                         my_t = Const<R>::inf();
                         my_prim = -1;
                         my_u = my_v = R(0);
+                        if (INST) inst = -1, my_inst = -1;
                         cur = sc.root_child;
                         if (sc.root_child == CHILD_EMPTY) finish();  // empty scene: a miss, the slot stays idle
                     }
@@ -467,7 +500,25 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
             const int32_t leaf = cur;
             const bool at_leaf = (uint32_t)leaf > (uint32_t)CHILD_EMPTY;
             if (COUNT && lane == 0 && tq_ballot(at_leaf) != 0) cnt_wleaf++;
-            if (at_leaf) {
+            if (INST && at_leaf && is_instance_word(leaf)) {
+                // enter the instance (uniform over the lanes of the group: `cur` is)
+                const InstTrace<R> &it = sc.inst_trace[instance_of_word(leaf)];
+                push_entry(sp, (tq_entry)(uint32_t)CHILD_EMPTY);  // return marker (key 0: never culled)
+                sp++;
+                const Vec3<R> o = ray.o, d = ray.d;
+                w_o = o, w_d = d;  // (instances do not nest: the saved ray is the world-space one)
+                if constexpr (QN) w_qr = qr;
+                else w_idx = idx, w_idy = idy, w_idz = idz;
+                ray.o = {it.inv[0] * o.x + it.inv[1] * o.y + it.inv[2] * o.z + it.inv[3],
+                         it.inv[4] * o.x + it.inv[5] * o.y + it.inv[6] * o.z + it.inv[7],
+                         it.inv[8] * o.x + it.inv[9] * o.y + it.inv[10] * o.z + it.inv[11]};
+                ray.d = {it.inv[0] * d.x + it.inv[1] * d.y + it.inv[2] * d.z, it.inv[4] * d.x + it.inv[5] * d.y + it.inv[6] * d.z,
+                         it.inv[8] * d.x + it.inv[9] * d.y + it.inv[10] * d.z};
+                idx = safe_inv(ray.d.x), idy = safe_inv(ray.d.y), idz = safe_inv(ray.d.z);
+                if constexpr (QN) qr = qray_make(it.grid_lo, it.grid_step, ray.o, idx, idy, idz);
+                inst = instance_of_word(leaf);
+                cur = it.root_child;
+            } else if (at_leaf) {
                 const int first = leaf_first(leaf), cnt = leaf_count(leaf);
                 if (COUNT && gl == 0) cnt_prims += (uint32_t)cnt, cnt_leaves++;
 #pragma unroll 1
@@ -485,6 +536,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                     if (take) {
                         my_t = t, my_u = u, my_v = v;
                         my_prim = first + k;
+                        if (INST) my_inst = inst;
                     }
                 }
                 tbest = tk_fmin(tbest, group_min<G>(my_t));

@@ -24,6 +24,7 @@ template <class R> struct HitT {
     int32_t shape;  // -1 = miss
     int32_t prim;   // index of the hit primitive in leaf order (-1 = miss)
     int32_t meta;   // PrimRec::meta of the hit primitive
+    int32_t inst;   // instance the primitive was reached through (two-level scenes), -1 = none
     R t, u, v;
 };
 
@@ -175,6 +176,7 @@ TK_HD void traverse(const DeviceScene<R> &sc, const RayT<R> &ray, Stack &stack, 
     hit.shape = -1;
     hit.prim = -1;
     hit.meta = 0;
+    hit.inst = -1;
     hit.t = ray.tmax;
     hit.u = hit.v = R(0);
     const R idx = safe_inv(ray.d.x), idy = safe_inv(ray.d.y), idz = safe_inv(ray.d.z);
@@ -249,6 +251,32 @@ TK_HD void traverse(const DeviceScene<R> &sc, const RayT<R> &ray, Stack &stack, 
                 cur = ch[0];
                 continue;
             }
+        } else if (is_instance_word(cur)) {
+            // two-level scenes: the prototype's tree in its object space (same t), as a nested traversal (the trace
+            // kernel does this on one stack with a return marker, tk_trace_quad.h)
+            const int32_t id = instance_of_word(cur);
+            const InstTrace<R> &it = sc.inst_trace[id];
+            const Vec3<R> o = ray.o, d = ray.d;
+            RayT<R> r2 = ray;
+            r2.o = {it.inv[0] * o.x + it.inv[1] * o.y + it.inv[2] * o.z + it.inv[3],
+                    it.inv[4] * o.x + it.inv[5] * o.y + it.inv[6] * o.z + it.inv[7],
+                    it.inv[8] * o.x + it.inv[9] * o.y + it.inv[10] * o.z + it.inv[11]};
+            r2.d = {it.inv[0] * d.x + it.inv[1] * d.y + it.inv[2] * d.z, it.inv[4] * d.x + it.inv[5] * d.y + it.inv[6] * d.z,
+                    it.inv[8] * d.x + it.inv[9] * d.y + it.inv[10] * d.z};
+            r2.tmax = tbest;
+            DeviceScene<R> sub = sc;
+            sub.root_child = it.root_child;
+            for (int a = 0; a < 3; a++) sub.grid_lo[a] = it.grid_lo[a], sub.grid_step[a] = it.grid_step[a];
+            HitT<R> h2;
+            Stack s2;
+            traverse<R, ANY_HIT, COUNT>(sub, r2, s2, h2, tc);
+            if (h2.prim >= 0 && (h2.t < tbest || hit.prim < 0 || h2.u > hit.u || (h2.u == hit.u && h2.v > hit.v))) {
+                tbest = h2.t;
+                hit = h2;
+                hit.inst = id;
+                hit.shape = sc.inst_shade[id].shape_base + h2.shape;
+                if (ANY_HIT) return;
+            }
         } else if (cur != CHILD_EMPTY) {
             const int first = leaf_first(cur), cnt = leaf_count(cur);
             if (COUNT) tc.leaves++;
@@ -263,6 +291,7 @@ TK_HD void traverse(const DeviceScene<R> &sc, const RayT<R> &ray, Stack &stack, 
                     hit.shape = p.shape_id;
                     hit.prim = first + k;
                     hit.meta = p.meta;
+                    hit.inst = -1;
                     hit.t = t;
                     hit.u = u;
                     hit.v = v;

@@ -68,6 +68,10 @@ class SceneData:
     lights: List[Light] = field(default_factory=list)
     materials: List[Material] = field(default_factory=list)
     images: List[np.ndarray] = field(default_factory=list)  # (h,w,3) f64
+    # EXTENSION (configs[4]): placements of prototype meshes, traversed on two levels — not flattened
+    instance_mesh: List[int] = field(default_factory=list)
+    instance_material: List[int] = field(default_factory=list)
+    instance_xform: List[np.ndarray] = field(default_factory=list)  # (3,4) object -> world
 
     @property
     def n_shapes(self):
@@ -109,6 +113,44 @@ class SceneData:
         self.shape_face = np.concatenate([self.shape_face, np.zeros(1, np.int32)])
         self.shape_area_light = np.concatenate([self.shape_area_light, np.full(1, al, np.int32)])
         return sid
+
+    def add_prototype(self, positions, indices, material_id, normals=None, uvs=None):
+        """a mesh that is only placed through add_instance: it gets no shapes of its own"""
+        self.meshes.append(Mesh(np.ascontiguousarray(positions, np.float64).reshape(-1, 3),
+                                np.ascontiguousarray(indices, np.int32).reshape(-1, 3), int(material_id),
+                                None if normals is None else np.ascontiguousarray(normals, np.float64).reshape(-1, 3),
+                                None if uvs is None else np.ascontiguousarray(uvs, np.float64).reshape(-1, 2)))
+        return len(self.meshes) - 1
+
+    def add_instance(self, mesh_id, xform, material_id=-1):
+        """EXTENSION (TakeInstance): place mesh `mesh_id` under the 3x4 affine object->world transform `xform`"""
+        x = np.ascontiguousarray(xform, np.float64).reshape(3, 4)
+        self.instance_mesh.append(int(mesh_id))
+        self.instance_material.append(int(material_id))
+        self.instance_xform.append(x)
+        return len(self.instance_mesh) - 1
+
+    def flattened(self):
+        """the same scene with every instance expanded to world-space triangles (one mesh per instance): what an
+        instanced render is specified to equal, to fp rounding"""
+        import copy
+
+        out = copy.copy(self)
+        out.meshes = list(self.meshes)
+        out.shape_kind, out.shape_ref = self.shape_kind.copy(), self.shape_ref.copy()
+        out.shape_face, out.shape_area_light = self.shape_face.copy(), self.shape_area_light.copy()
+        out.lights = list(self.lights)
+        out.instance_mesh, out.instance_material, out.instance_xform = [], [], []
+        for mid, mat, x in zip(self.instance_mesh, self.instance_material, self.instance_xform):
+            m = self.meshes[mid]
+            pos = m.positions @ x[:, :3].T + x[:, 3]
+            nrm = None
+            if m.normals is not None:
+                # rows: (L^-T n)^T = n^T L^-1; NOT re-normalised per vertex — interpolation commutes with the linear
+                # map only then (the interpolated normal is normalised at the hit, src/shape.cpp:105)
+                nrm = m.normals @ np.linalg.inv(x[:, :3])
+            out.add_mesh(pos, m.indices, m.material_id if mat < 0 else mat, normals=nrm, uvs=m.uvs)
+        return out
 
     def add_envmap(self, image, scale=(1.0, 1.0, 1.0)):
         """Environment-map light (EXTENSION, TakeLight kind 2 — the reference has only `background`): an
@@ -196,6 +238,12 @@ class SceneData:
         d.n_lights, d.lights = len(self.lights), lights
         d.n_materials, d.materials = len(self.materials), mats
         d.n_images, d.images = len(self.images), images
+        inst = (D.TakeInstance * max(len(self.instance_mesh), 1))()
+        for i, (mid, mat, x) in enumerate(zip(self.instance_mesh, self.instance_material, self.instance_xform)):
+            inst[i].mesh_id, inst[i].material_id = mid, mat
+            inst[i].xform = (C.c_double * 12)(*x.reshape(-1))
+        keep.append(inst)
+        d.n_instances, d.instances = len(self.instance_mesh), inst
         return d, keep
 
 

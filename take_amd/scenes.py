@@ -105,12 +105,14 @@ def soup_scene(n_tris, width, height, spp, seed=1234, jitter=None, max_depth=50,
     return sd
 
 
-def instanced_scene(n_instances, tris_per_mesh, width, height, spp, seed=4321, max_depth=50):
-    """BASELINE configs[4]: `n_instances` copies of one `tris_per_mesh`-triangle mesh under random rigid transforms,
-    materials round-robin over the reference's real BSDFs (Diffuse, Plastic, Phong, BlinnPhong, three
-    BlinnPhongMicrofacet exponents) — the divergence stress.  The reference has no instancing: the
-    instances are FLATTENED to world-space triangles here (10M triangles = 1.1 GB of a 288 GB device), which is
-    also what "instanced == flattened geometry" would be checked against.  Same box, light and camera as soup_scene."""
+def instanced_scene(n_instances, tris_per_mesh, width, height, spp, seed=4321, max_depth=50, flatten=False):
+    """BASELINE configs[4]: `n_instances` placements of one `tris_per_mesh`-triangle mesh under random rigid
+    transforms, materials round-robin over the reference's real BSDFs (Diffuse, Plastic, Phong, BlinnPhong, three
+    BlinnPhongMicrofacet exponents) — the divergence stress.  The reference has no instancing.
+    Default: true instancing (TakeInstance, an extension): ONE prototype mesh in object space + one transform and
+    material per placement, traversed on two levels.  flatten=True: the same geometry expanded to world-space
+    triangles (SceneData.flattened) — what the instanced render is specified to equal, to fp rounding, and the only
+    form the reference's own scene model can express.  Same box, light and camera as soup_scene."""
     sd = SceneData(width=width, height=height, lookfrom=(0.0, 0.0, 3.9), lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0),
                    vfov=vfov_from_xfov(39.0, width, height), background=(0.0, 0.0, 0.0), spp=spp, max_depth=max_depth)
     white = sd.add_material(D.MAT_DIFFUSE, (0.73, 0.73, 0.73))
@@ -126,8 +128,7 @@ def instanced_scene(n_instances, tris_per_mesh, width, height, spp, seed=4321, m
             sd.add_material(D.MAT_BLINN_PHONG_MICROFACET, (0.8, 0.7, 0.3), (500.0,))]
     rng = np.random.default_rng(seed)
     # the prototype: a small cloud of triangles around the origin (radius ~0.08)
-    proto, _ = soup_triangles(tris_per_mesh, seed + 1, 0.07, 0.012)
-    proto = proto.reshape(-1, 3)
+    proto, pidx = soup_triangles(tris_per_mesh, seed + 1, 0.07, 0.012)
     # random rigid transforms: rotation from a unit quaternion, translation inside the box
     q = rng.normal(size=(n_instances, 4))
     q /= np.linalg.norm(q, axis=1, keepdims=True)
@@ -136,17 +137,10 @@ def instanced_scene(n_instances, tris_per_mesh, width, height, spp, seed=4321, m
                     np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
                     np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], 1)
     trans = rng.uniform(-0.85, 0.85, (n_instances, 3))
-    k = len(mats)
-    idx = np.arange(3 * tris_per_mesh, dtype=np.int32).reshape(-1, 3)
-    for j, m in enumerate(mats):  # one mesh per material: all instances of that material, flattened
-        sel = np.arange(j, n_instances, k)
-        if len(sel) == 0:
-            continue
-        world = np.einsum("iab,vb->iva", rot[sel], proto) + trans[sel, None, :]
-        n = len(sel)
-        big_idx = (idx[None, :, :] + (np.arange(n, dtype=np.int32) * 3 * tris_per_mesh)[:, None, None]).reshape(-1, 3)
-        sd.add_mesh(world.reshape(-1, 3), big_idx, m)
-    return sd
+    mesh = sd.add_prototype(proto, pidx, white)
+    for i in range(n_instances):
+        sd.add_instance(mesh, np.concatenate([rot[i], trans[i][:, None]], axis=1), mats[i % len(mats)])
+    return sd.flattened() if flatten else sd
 
 
 def write_reference_inputs(sd: SceneData, directory, name="scene"):

@@ -93,6 +93,7 @@ template <class R> int render_t(const TakeSceneDesc &desc, const TakeRenderOpts 
                 n_nodes += tc.nodes, n_prims += tc.prims, n_closest++;
                 max_stack = std::max<uint64_t>(max_stack, stack.max_level);
                 st.I_(S_HIT, slot) = hit.prim;
+                st.I_(S_INST, slot) = hit.inst;
                 st.R_(S_HT, slot) = hit.t;
                 st.R_(S_HU, slot) = hit.u;
                 st.R_(S_HV, slot) = hit.v;
