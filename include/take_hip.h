@@ -280,6 +280,26 @@ int take_hip_trace_any(TakeScene *scene, const void *rays, int64_t n, int32_t *o
 int take_hip_trace_closest_device(TakeScene *scene, const void *d_rays, int64_t n, void *d_hits,
                                   int32_t count_mode, void *stream);
 
+/* ---- several GPUs from ONE process (the C++ host of the reference is a single process: main.cpp -> render()).
+ * Replaces the thread pool of src/parallel.cpp:183-237 for the drop-in: the scene is built once per device
+ * (replicated), device k of n renders the 4-row strips s with s % n == k on its own host thread, and the strips are
+ * gathered on the first device with hipMemcpyPeerAsync (xGMI between the GPUs of a node) — the only exchange.  The
+ * image is identical for every n (pixel keys do not depend on the sharding).  `devices` lists the HIP devices to use
+ * (NULL: 0 .. n_gpus-1); a device may appear more than once (logical shards of one GPU: how the sharding is tested
+ * on a one-GPU box).  (A multi-process job — one process per GPU, RCCL gather — uses plain scene handles with
+ * strip_first / strip_stride instead: take_amd/dist.py, bench.py.)                                               */
+typedef struct TakeSceneGroup TakeSceneGroup; /* opaque */
+int take_hip_group_create(const TakeSceneDesc *desc, const TakeBuildOpts *opts, int32_t n_gpus, const int32_t *devices,
+                          TakeSceneGroup **out);
+int take_hip_group_destroy(TakeSceneGroup *group);
+/* Whole image (height * width * 3 Real, row 0 = top) into host memory / into memory of the group's first device.
+ * opts->strip_first / strip_stride are ignored (the group shards by itself). */
+int take_hip_group_render(TakeSceneGroup *group, const TakeRenderOpts *opts, void *rgb_out_host);
+int take_hip_group_render_device(TakeSceneGroup *group, const TakeRenderOpts *opts, void *d_rgb_out);
+int take_hip_group_size(const TakeSceneGroup *group);
+/* counters of shard k's last render (ms_total etc. per device: load balance) */
+int take_hip_group_get_counters(const TakeSceneGroup *group, int32_t k, TakeCounters *out);
+
 int take_hip_get_counters(const TakeScene *scene, TakeCounters *out);
 /* enable per-kernel HIP-event timing + counting mode for subsequent renders
  * (bit 0 = event timing, bit 1 = visit counters; both off by default) */

@@ -20,6 +20,8 @@ EXPORTS = [
     "take_hip_scene_destroy", "take_hip_render", "take_hip_render_device", "take_hip_render_rows",
     "take_hip_trace_closest", "take_hip_trace_any", "take_hip_trace_closest_device", "take_hip_get_counters",
     "take_hip_set_instrumentation", "take_hip_scene_stats", "take_hip_debug_table",
+    "take_hip_group_create", "take_hip_group_destroy", "take_hip_group_render", "take_hip_group_render_device",
+    "take_hip_group_size", "take_hip_group_get_counters",
 ]
 
 
@@ -62,6 +64,13 @@ def lib():
         L.take_hip_set_instrumentation.argtypes = [C.c_void_p, C.c_int32]
         L.take_hip_scene_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                            C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+        L.take_hip_group_create.argtypes = [C.POINTER(D.TakeSceneDesc), C.POINTER(D.TakeBuildOpts), C.c_int32,
+                                            C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]
+        L.take_hip_group_destroy.argtypes = [C.c_void_p]
+        L.take_hip_group_render.argtypes = [C.c_void_p, C.POINTER(D.TakeRenderOpts), C.c_void_p]
+        L.take_hip_group_render_device.argtypes = [C.c_void_p, C.POINTER(D.TakeRenderOpts), C.c_void_p]
+        L.take_hip_group_size.argtypes = [C.c_void_p]
+        L.take_hip_group_get_counters.argtypes = [C.c_void_p, C.c_int32, C.POINTER(D.TakeCounters)]
         _LIB = L
     return _LIB
 
@@ -183,3 +192,50 @@ class Scene:
         nn, npr, dep, by = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int64()
         _check(lib().take_hip_scene_stats(self.h, C.byref(nn), C.byref(npr), C.byref(dep), C.byref(by)))
         return {"n_nodes": nn.value, "n_prims": npr.value, "depth": dep.value, "device_bytes": by.value}
+
+
+class SceneGroup:
+    """The scene replicated on several GPUs of ONE process (take_hip_group_*): what the reference's single-process
+    C++ host uses in place of its thread pool.  `devices`: HIP device per shard; a device may repeat (logical shards)."""
+
+    def __init__(self, scene_data, devices, precision=D.TAKE_PRECISION_F32, bvh_threads=0, max_leaf_size=0,
+                 builder=D.TAKE_BUILDER_HOST_SAH):
+        self.sd = scene_data
+        self.precision = precision
+        self.dtype = np.float64 if precision == D.TAKE_PRECISION_F64 else np.float32
+        desc, keep = scene_data.to_desc()
+        opts = D.TakeBuildOpts(precision, bvh_threads, max_leaf_size, builder)
+        devs = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(lib().take_hip_group_create(C.byref(desc), C.byref(opts), len(devices), devs, C.byref(h)))
+        self.h = h
+        del keep
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().take_hip_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return _check(lib().take_hip_group_size(self.h))
+
+    def render(self, spp=None, max_depth=None, seed=0, samples_per_batch=0, integrator=0):
+        """-> (H, W, 3) host image assembled on the group's first device"""
+        o = D.TakeRenderOpts()
+        o.spp = int(self.sd.spp if spp is None else spp)
+        o.max_depth = int(self.sd.max_depth if max_depth is None else max_depth)
+        o.seed, o.samples_per_batch, o.integrator = int(seed), int(samples_per_batch), int(integrator)
+        out = np.zeros((self.sd.height, self.sd.width, 3), self.dtype)
+        _check(lib().take_hip_group_render(self.h, C.byref(o), out.ctypes.data))
+        return out
+
+    def counters(self, k):
+        c = D.TakeCounters()
+        _check(lib().take_hip_group_get_counters(self.h, int(k), C.byref(c)))
+        return c.as_dict()

@@ -998,6 +998,191 @@ int take_hip_debug_table(int32_t kind, int32_t precision, const double *in, int6
     return rc;
 }
 
+// ------------------------------------------------------------------------------------------------ scene groups
+}  // extern "C"
+
+struct TakeSceneGroup {
+    std::vector<TakeScene *> scenes;  // one per shard, each on its device
+    std::vector<void *> staging;      // on the first device: shard k's compact rows (k > 0), copied peer to peer
+    std::vector<int32_t *> d_rows;    // on the first device: image row of each compact row of shard k
+    std::vector<int> n_rows;
+    void *d_full = nullptr;           // on the first device: the assembled image (take_hip_group_render)
+    int width = 0, height = 0;
+    bool f64 = false;
+};
+
+namespace {
+// compact rows of one shard -> their rows of the full image
+template <class R>
+__global__ void __launch_bounds__(BLOCK) k_place_rows(const R *__restrict__ src, const int32_t *__restrict__ rows, int n_rows,
+                                                      int row_words, R *dst) {
+    const int64_t total = (int64_t)n_rows * row_words;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
+        const int r = (int)(i / row_words), c = (int)(i % row_words);
+        dst[(int64_t)rows[r] * row_words + c] = src[i];
+    }
+}
+
+void group_release(TakeSceneGroup *g) {
+    if (!g) return;
+    if (!g->scenes.empty() && g->scenes[0]) {
+        DeviceGuard guard(g->scenes[0]->device);
+        for (void *p : g->staging)
+            if (p) (void)hipFree(p);
+        for (int32_t *p : g->d_rows)
+            if (p) (void)hipFree(p);
+        if (g->d_full) (void)hipFree(g->d_full);
+    }
+    for (TakeScene *ts : g->scenes) take_hip_scene_destroy(ts);
+    delete g;
+}
+
+int group_render(TakeSceneGroup *g, const TakeRenderOpts &opts, void *d_out) {
+    const int n = (int)g->scenes.size();
+    const size_t esz = g->f64 ? 8 : 4;
+    const int row_words = g->width * 3;
+    // every shard renders its strips on its own device, from its own host thread
+    std::vector<int> rc(n, TAKE_OK);
+    std::vector<std::string> err(n);
+    std::vector<std::thread> pool;
+    for (int k = 0; k < n; k++)
+        pool.emplace_back([&, k] {
+            TakeScene *ts = g->scenes[k];
+            TakeRenderOpts o = opts;
+            o.strip_first = k, o.strip_stride = n;
+            if (g->n_rows[k] == 0) return;
+            DeviceGuard guard(ts->device);
+            if (!guard.ok) {
+                rc[k] = TAKE_E_DEVICE, err[k] = "cannot make the shard's device current";
+                return;
+            }
+            int r = g->f64 ? ensure_workspace(ts->d, 0, (int64_t)g->n_rows[k] * g->width)
+                           : ensure_workspace(ts->f, 0, (int64_t)g->n_rows[k] * g->width);
+            if (!r) r = g->f64 ? render_impl<double>(ts, o, ts->d.out.p, nullptr) : render_impl<float>(ts, o, ts->f.out.p, nullptr);
+            if (!r && k > 0) {  // the one exchange: this shard's rows to the first device
+                const hipError_t e = hipMemcpyPeer(g->staging[k], g->scenes[0]->device, g->f64 ? (void *)ts->d.out.p : (void *)ts->f.out.p,
+                                                   ts->device, (size_t)g->n_rows[k] * row_words * esz);
+                if (e != hipSuccess) r = TAKE_E_DEVICE, g_error = std::string("hipMemcpyPeer: ") + hipGetErrorString(e);
+            }
+            rc[k] = r;
+            if (r) err[k] = g_error;  // g_error is thread-local: hand the message to the caller's thread
+        });
+    for (auto &t : pool) t.join();
+    for (int k = 0; k < n; k++)
+        if (rc[k]) return fail(rc[k], "shard " + std::to_string(k) + ": " + err[k]);
+    // assemble on the first device
+    DeviceGuard guard(g->scenes[0]->device);
+    if (!guard.ok) return fail(TAKE_E_DEVICE, "cannot make the first device current");
+    for (int k = 0; k < n; k++) {
+        if (g->n_rows[k] == 0) continue;
+        const void *src = k == 0 ? (g->f64 ? (void *)g->scenes[0]->d.out.p : (void *)g->scenes[0]->f.out.p) : g->staging[k];
+        const int64_t total = (int64_t)g->n_rows[k] * row_words;
+        const dim3 grid((unsigned)std::min<int64_t>((total + BLOCK - 1) / BLOCK, 4096));
+        if (g->f64) hipLaunchKernelGGL((k_place_rows<double>), grid, dim3(BLOCK), 0, nullptr, (const double *)src, g->d_rows[k], g->n_rows[k], row_words, (double *)d_out);
+        else hipLaunchKernelGGL((k_place_rows<float>), grid, dim3(BLOCK), 0, nullptr, (const float *)src, g->d_rows[k], g->n_rows[k], row_words, (float *)d_out);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return TAKE_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int take_hip_group_create(const TakeSceneDesc *desc, const TakeBuildOpts *opts, int32_t n_gpus, const int32_t *devices,
+                          TakeSceneGroup **out) {
+    if (!desc || !out) return fail(TAKE_E_INVALID, "null argument");
+    *out = nullptr;
+    const int nd = check_device();
+    if (nd < 0) return nd;
+    if (n_gpus <= 0 || n_gpus > 64) return fail(TAKE_E_INVALID, "n_gpus must be in 1..64");
+    for (int k = 0; k < n_gpus; k++) {
+        const int dev = devices ? devices[k] : k;
+        if (dev < 0 || dev >= nd) return fail(TAKE_E_INVALID, "device " + std::to_string(dev) + " of shard " + std::to_string(k) + " is not visible (" + std::to_string(nd) + " devices)");
+    }
+    TakeSceneGroup *g = new (std::nothrow) TakeSceneGroup();
+    if (!g) return fail(TAKE_E_NOMEM, "out of host memory");
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = TAKE_OK;
+    for (int k = 0; k < n_gpus && !rc; k++) {
+        const int dev = devices ? devices[k] : k;
+        if (hipSetDevice(dev) != hipSuccess) {
+            rc = fail(TAKE_E_DEVICE, "hipSetDevice failed");
+            break;
+        }
+        TakeScene *ts = nullptr;
+        rc = take_hip_scene_create(desc, opts, &ts);  // (the build is deterministic: every replica holds the same tree)
+        if (!rc) g->scenes.push_back(ts);
+    }
+    if (!rc) {
+        TakeScene *t0 = g->scenes[0];
+        g->f64 = t0->precision == TAKE_PRECISION_F64;
+        g->width = g->f64 ? t0->d.host.cam.width : t0->f.host.cam.width;
+        g->height = g->f64 ? t0->d.host.cam.height : t0->f.host.cam.height;
+        const size_t esz = g->f64 ? 8 : 4;
+        g->staging.assign(n_gpus, nullptr), g->d_rows.assign(n_gpus, nullptr), g->n_rows.assign(n_gpus, 0);
+        if (hipSetDevice(t0->device) != hipSuccess) rc = fail(TAKE_E_DEVICE, "hipSetDevice failed");
+        for (int k = 0; k < n_gpus && !rc; k++) {
+            std::vector<int32_t> rows((size_t)g->height);
+            const int nr = rows_of(g->height, k, n_gpus, rows.data());
+            g->n_rows[k] = nr;
+            if (nr == 0) continue;
+            if (hipMalloc((void **)&g->d_rows[k], (size_t)nr * sizeof(int32_t)) != hipSuccess ||
+                hipMemcpy(g->d_rows[k], rows.data(), (size_t)nr * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
+                (k > 0 && hipMalloc(&g->staging[k], (size_t)nr * g->width * 3 * esz) != hipSuccess))
+                rc = fail(TAKE_E_NOMEM, "out of device memory for the strip staging buffers");
+            if (!rc && k > 0 && g->scenes[k]->device != t0->device) {
+                // direct peer access if the fabric offers it (hipMemcpyPeer works either way)
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, t0->device, g->scenes[k]->device) == hipSuccess && can)
+                    (void)hipDeviceEnablePeerAccess(g->scenes[k]->device, 0);
+                (void)hipGetLastError();
+            }
+        }
+    }
+    (void)hipSetDevice(prev);
+    if (rc) {
+        const std::string msg = g_error;
+        group_release(g);
+        return fail(rc, msg);
+    }
+    *out = g;
+    return TAKE_OK;
+}
+
+int take_hip_group_destroy(TakeSceneGroup *g) {
+    group_release(g);
+    return TAKE_OK;
+}
+int take_hip_group_size(const TakeSceneGroup *g) { return g ? (int)g->scenes.size() : fail(TAKE_E_INVALID, "null group"); }
+
+int take_hip_group_render_device(TakeSceneGroup *g, const TakeRenderOpts *opts, void *d_rgb_out) {
+    if (!g || !opts || !d_rgb_out) return fail(TAKE_E_INVALID, "null argument");
+    return group_render(g, *opts, d_rgb_out);
+}
+
+int take_hip_group_render(TakeSceneGroup *g, const TakeRenderOpts *opts, void *rgb_out_host) {
+    if (!g || !opts || !rgb_out_host) return fail(TAKE_E_INVALID, "null argument");
+    const size_t bytes = (size_t)g->width * g->height * 3 * (g->f64 ? 8 : 4);
+    DeviceGuard guard(g->scenes[0]->device);
+    if (!guard.ok) return fail(TAKE_E_DEVICE, "cannot make the first device current");
+    if (!g->d_full && hipMalloc(&g->d_full, bytes) != hipSuccess) {
+        g->d_full = nullptr;
+        return fail(TAKE_E_NOMEM, "out of device memory for the assembled image");
+    }
+    const int rc = group_render(g, *opts, g->d_full);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(rgb_out_host, g->d_full, bytes, hipMemcpyDeviceToHost));
+    return TAKE_OK;
+}
+
+int take_hip_group_get_counters(const TakeSceneGroup *g, int32_t k, TakeCounters *out) {
+    if (!g || !out || k < 0 || k >= (int)g->scenes.size()) return fail(TAKE_E_INVALID, "bad argument");
+    *out = g->scenes[k]->counters;
+    return TAKE_OK;
+}
+
 int take_hip_get_counters(const TakeScene *ts, TakeCounters *out) {
     if (!ts || !out) return fail(TAKE_E_INVALID, "null argument");
     *out = ts->counters;

@@ -13,8 +13,14 @@
 //   TAKE_HIP_PRECISION=f64   render in double (default f32)
 //   TAKE_HIP_SEED=<n>        global seed (the reference seeds from std::random_device, src/render.cpp:60)
 //   TAKE_HIP_DUMP_PFM=<file> also write the float image through the reference's imwrite (tests)
+//   TAKE_HIP_GPUS=<n>        render on the first n GPUs of the node from this one process (take_hip_group_*: scene
+//                            replicated, 4-row strips dealt round-robin, strips gathered peer to peer on GPU 0) —
+//                            the counterpart of the reference's `-t <threads>` (src/parallel.cpp:183-237);
+//                            "n x d" forms like TAKE_HIP_GPUS=4:0 put all 4 shards on device 0 (tests)
 #include <chrono>
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <string>
 #include <vector>
@@ -64,8 +70,16 @@ Image3 render(const std::vector<std::string> &params) {
     const bool f64 = prec && std::string(prec) == "f64";
     TakeBuildOpts bo{};
     bo.precision = f64 ? TAKE_PRECISION_F64 : TAKE_PRECISION_F32;
-    TakeScene *gpu = nullptr;
-    if (take_hip_scene_create(&flat.desc, &bo, &gpu) != TAKE_OK) gpu_error("scene_create");
+    // TAKE_HIP_GPUS: "<n>" or "<n>:<device>" (all shards on one device)
+    int n_gpus = 1, one_device = -1;
+    if (const char *g = std::getenv("TAKE_HIP_GPUS")) {
+        n_gpus = std::max(1, std::atoi(g));
+        if (const char *c = std::strchr(g, ':')) one_device = std::atoi(c + 1);
+    }
+    std::vector<int32_t> devices(n_gpus);
+    for (int k = 0; k < n_gpus; k++) devices[k] = one_device >= 0 ? one_device : k;
+    TakeSceneGroup *gpu = nullptr;
+    if (take_hip_group_create(&flat.desc, &bo, n_gpus, devices.data(), &gpu) != TAKE_OK) gpu_error("group_create");
     std::cout << "Finish building BVH. Took " << sw.lap() << " seconds." << std::endl;
 
     // was: parallel_for over 16x16 tiles, path_tracing per sample                        src/render.cpp:59-82
@@ -74,24 +88,22 @@ Image3 render(const std::vector<std::string> &params) {
     ro.spp = scene.options.spp;
     ro.max_depth = scene.options.max_depth;
     ro.seed = std::getenv("TAKE_HIP_SEED") ? std::strtoull(std::getenv("TAKE_HIP_SEED"), nullptr, 10) : 0;
-    ro.strip_first = 0;
-    ro.strip_stride = 1;
     Image3 img(scene.camera.width, scene.camera.height);
     const size_t n = (size_t)img.width * img.height;
     int rc;
     if (f64) {
         static_assert(sizeof(Vector3) == 3 * sizeof(double), "Image3 is tightly packed double RGB");
-        rc = take_hip_render(gpu, &ro, img.data.data());  // Image3 order: row 0 = top (src/render.cpp:78)
+        rc = take_hip_group_render(gpu, &ro, img.data.data());  // Image3 order: row 0 = top (src/render.cpp:78)
     } else {
         std::vector<float> rgb(3 * n);
-        rc = take_hip_render(gpu, &ro, rgb.data());
+        rc = take_hip_group_render(gpu, &ro, rgb.data());
         for (size_t i = 0; i < n; i++) img.data[i] = Vector3{rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
     }
     if (rc != TAKE_OK) {
-        take_hip_scene_destroy(gpu);
+        take_hip_group_destroy(gpu);
         gpu_error("render");
     }
-    take_hip_scene_destroy(gpu);
+    take_hip_group_destroy(gpu);
     std::cout << std::endl << "Finish building rendering. Took " << sw.lap() << " seconds." << std::endl;
     if (const char *dump = std::getenv("TAKE_HIP_DUMP_PFM")) imwrite(dump, img);
     return img;
