@@ -62,8 +62,9 @@ def parse_args():
     ap.add_argument("--flatten", action="store_true",
                     help="with --instanced: expand the placements to world-space triangles (what the reference's scene "
                          "model can express; the instanced render is specified to equal it)")
-    ap.add_argument("--builder", default="host", choices=["host", "device"],
-                    help="device = LBVH built on the GPU (fast build, slower traversal; not the default workload)")
+    ap.add_argument("--builder", default="host", choices=["host", "device", "auto"],
+                    help="host = binned SAH (default: the best trees); device = records + LBVH built on the GPU (fast "
+                         "build, 2-6 %% slower traversal); auto = the library's default (host below 4M shapes)")
     ap.add_argument("--max-leaf", type=int, default=0, help="primitives per BVH leaf (0 = builder default)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3],
                     help="BASELINE.json configs index: 2 = 1920x1080x256 spp per GPU (weak scaling, default); 3 = 4096x4096, "
@@ -250,7 +251,7 @@ def main():
         sd = scenes.soup_scene(args.tris, args.width, args.height, spp=spp_total, max_depth=args.max_depth,
                                materials=args.materials, envmap=(2048, 1024) if args.envmap else None)
     scene = capi.Scene(sd, precision=D.TAKE_PRECISION_F32, max_leaf_size=args.max_leaf,
-                       builder=D.TAKE_BUILDER_DEVICE_LBVH if args.builder == "device" else D.TAKE_BUILDER_HOST_SAH)
+                       builder={"device": D.TAKE_BUILDER_DEVICE_LBVH, "host": D.TAKE_BUILDER_HOST_SAH, "auto": D.TAKE_BUILDER_AUTO}[args.builder])
     t_setup = time.time() - t0
     stats = scene.stats()
     rows = strip_rows(args.height, rank, world)

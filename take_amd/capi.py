@@ -21,7 +21,7 @@ EXPORTS = [
     "take_hip_trace_closest", "take_hip_trace_any", "take_hip_trace_closest_device", "take_hip_get_counters",
     "take_hip_set_instrumentation", "take_hip_scene_stats", "take_hip_debug_table",
     "take_hip_group_create", "take_hip_group_destroy", "take_hip_group_render", "take_hip_group_render_device",
-    "take_hip_group_size", "take_hip_group_get_counters",
+    "take_hip_group_size", "take_hip_group_get_counters", "take_hip_pack_exr_scanlines", "take_hip_render_exr_scanlines",
 ]
 
 
@@ -64,6 +64,8 @@ def lib():
         L.take_hip_set_instrumentation.argtypes = [C.c_void_p, C.c_int32]
         L.take_hip_scene_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                            C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+        L.take_hip_pack_exr_scanlines.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.take_hip_render_exr_scanlines.argtypes = [C.c_void_p, C.POINTER(D.TakeRenderOpts), C.c_void_p]
         L.take_hip_group_create.argtypes = [C.POINTER(D.TakeSceneDesc), C.POINTER(D.TakeBuildOpts), C.c_int32,
                                             C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]
         L.take_hip_group_destroy.argtypes = [C.c_void_p]
@@ -106,7 +108,7 @@ class Scene:
     """A scene resident on the current HIP device: flattened `Scene` + wide BVH in HBM."""
 
     def __init__(self, scene_data, precision=D.TAKE_PRECISION_F32, bvh_threads=0, max_leaf_size=0,
-                 builder=D.TAKE_BUILDER_HOST_SAH):
+                 builder=D.TAKE_BUILDER_AUTO):
         self.sd = scene_data
         self.precision = precision
         self.dtype = np.float64 if precision == D.TAKE_PRECISION_F64 else np.float32
@@ -158,6 +160,16 @@ class Scene:
         o = self._opts(spp, max_depth, seed, ray_epsilon, strip_first, strip_stride, samples_per_batch, integrator)
         _check(lib().take_hip_render_device(self.h, C.byref(o), C.c_void_p(d_ptr), C.c_void_p(stream or 0)))
 
+    def render_exr_scanlines(self, spp=None, max_depth=None, seed=0, samples_per_batch=0, integrator=0):
+        """Render and convert on the device: -> uint16 (H, 3, W), per scanline the B, G, R halves of the reference's
+        image.exr (take_amd.exr.write_exr_scanlines frames them into the file)."""
+        spp = self.sd.spp if spp is None else spp
+        max_depth = self.sd.max_depth if max_depth is None else max_depth
+        o = self._opts(spp, max_depth, seed, 0.0, 0, 1, samples_per_batch, integrator)
+        out = np.zeros((self.sd.height, 3, self.sd.width), np.uint16)
+        _check(lib().take_hip_render_exr_scanlines(self.h, C.byref(o), out.ctypes.data))
+        return out
+
     def trace_closest(self, rays_abi):
         """rays_abi: (n,8) array in TakeRayF/D layout (org3 tmin dir3 tmax) -> structured hits"""
         rays = np.ascontiguousarray(rays_abi, self.dtype)
@@ -199,7 +211,7 @@ class SceneGroup:
     C++ host uses in place of its thread pool.  `devices`: HIP device per shard; a device may repeat (logical shards)."""
 
     def __init__(self, scene_data, devices, precision=D.TAKE_PRECISION_F32, bvh_threads=0, max_leaf_size=0,
-                 builder=D.TAKE_BUILDER_HOST_SAH):
+                 builder=D.TAKE_BUILDER_AUTO):
         self.sd = scene_data
         self.precision = precision
         self.dtype = np.float64 if precision == D.TAKE_PRECISION_F64 else np.float32

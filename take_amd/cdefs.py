@@ -67,8 +67,9 @@ class TakeBuildOpts(C.Structure):
                 ("builder", C.c_int32)]
 
 
-TAKE_BUILDER_HOST_SAH = 0
+TAKE_BUILDER_AUTO = 0          # host SAH below 4M shapes, device LBVH from there on
 TAKE_BUILDER_DEVICE_LBVH = 1
+TAKE_BUILDER_HOST_SAH = 2
 
 
 class TakeRenderOpts(C.Structure):

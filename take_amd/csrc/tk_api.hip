@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -288,8 +289,73 @@ template <class R> int build_bvh_device_any(SceneT<R> &sc, int max_leaf, bool co
     return 1;
 }
 
+// Primitive records on the device from the caller's arrays (tk_build_gpu.h::k_make_prims): the mesh positions go up as
+// they are (double, one copy per mesh, no host staging), the face indices are the validated concatenation the shading
+// side keeps anyway (sc.face_idx, uploaded here), the four shape arrays go up as they are.
+int make_prims_on_device(SceneT<float> &sc, const TakeSceneDesc &d) {
+    using namespace lbvh;
+    const int n = (int)d.n_shapes;
+    HostScene<float> &h = sc.host;
+    std::vector<MeshSrc> ms(d.n_meshes);
+    int64_t nv = 0;
+    for (int i = 0; i < d.n_meshes; i++) {
+        const MeshInfo &mi = h.meshes[i];
+        ms[i] = MeshSrc{nv, mi.fbase, mi.material, h.materials[mi.material].tag, (mi.nbase >= 0 || mi.uvbase >= 0) ? 1 : 0};
+        nv += d.meshes[i].n_vertices;
+    }
+    std::vector<SphereSrc> ss(d.n_spheres);
+    for (int i = 0; i < d.n_spheres; i++) {
+        const TakeSphere &s = d.spheres[i];
+        ss[i] = SphereSrc{{s.center[0], s.center[1], s.center[2]}, s.radius, s.material_id, h.materials[s.material_id].tag};
+    }
+    DevBuf<double> d_pos;
+    DevBuf<int32_t> d_kind, d_ref, d_face, d_al;
+    DevBuf<MeshSrc> d_ms;
+    DevBuf<SphereSrc> d_ss;
+    struct Cleanup {
+        std::function<void()> f;
+        ~Cleanup() { f(); }
+    } cleanup{[&] { d_pos.release(), d_kind.release(), d_ref.release(), d_face.release(), d_al.release(), d_ms.release(), d_ss.release(); }};
+    HIP_TRY(d_pos.alloc(3 * (size_t)std::max<int64_t>(nv, 1)));
+    for (int i = 0; i < d.n_meshes; i++)
+        if (d.meshes[i].n_vertices > 0)
+            HIP_TRY(hipMemcpyAsync(d_pos.p + 3 * ms[i].pos_off, d.meshes[i].positions, sizeof(double) * 3 * (size_t)d.meshes[i].n_vertices,
+                                   hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(sc.face_idx.upload(h.face_idx));
+    auto up = [&](DevBuf<int32_t> &b, const int32_t *src) -> hipError_t {
+        hipError_t e = b.alloc((size_t)n);
+        return e != hipSuccess ? e : hipMemcpyAsync(b.p, src, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, nullptr);
+    };
+    HIP_TRY(up(d_kind, d.shape_kind));
+    HIP_TRY(up(d_ref, d.shape_ref));
+    HIP_TRY(up(d_face, d.shape_face));
+    HIP_TRY(up(d_al, d.shape_area_light));
+    HIP_TRY(d_ms.upload(ms));
+    HIP_TRY(d_ss.upload(ss));
+    HIP_TRY(sc.prims.alloc((size_t)n));
+    hipLaunchKernelGGL(k_make_prims, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, nullptr, d_kind.p, d_ref.p, d_face.p, d_al.p,
+                       d_ms.p, d_pos.p, sc.face_idx.p, d_ss.p, n, sc.prims.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return TAKE_OK;
+}
+template <class R> int make_prims_on_device(SceneT<R> &, const TakeSceneDesc &) { return 1; }
+
+// phase timer of scene_create (TAKE_HIP_VERBOSE=1 prints the phases to stderr)
+struct PhaseClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    bool on = std::getenv("TAKE_HIP_VERBOSE") != nullptr;
+    void lap(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[take_hip] scene_create: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, const TakeBuildOpts &opts) {
     SceneT<R> &sc = pick<R>(ts);
+    PhaseClock clock;
     int threads = opts.bvh_threads > 0 ? opts.bvh_threads : (int)std::thread::hardware_concurrency();
     if (threads <= 0) threads = 1;
     int max_leaf = opts.max_leaf_size;
@@ -299,24 +365,38 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     const char *fmt_env = std::getenv("TAKE_HIP_NODES");
     const std::string fmt = fmt_env ? fmt_env : "";
     // device build: f32 scenes with enough primitives to make a tree; otherwise (and as its fall-back) the host SAH build
-    bool on_device = opts.builder == TAKE_BUILDER_DEVICE_LBVH && sizeof(R) == 4 && desc.n_shapes >= 8 && desc.n_instances == 0;
-    std::string err = prepare_scene<R>(desc, max_leaf, threads, sc.host, !on_device);
+    // builder: AUTO = host SAH (best trees) up to 4M shapes, device LBVH beyond (f32): at 10M triangles the host build
+    // is 6 s of setup against 0.2 s, for 2-6 % of traversal speed
+    const bool want_device = opts.builder == TAKE_BUILDER_DEVICE_LBVH ||
+                             (opts.builder == TAKE_BUILDER_AUTO && desc.n_shapes >= TAKE_AUTO_DEVICE_BUILD_SHAPES);
+    bool on_device = want_device && sizeof(R) == 4 && desc.n_shapes >= 8 && desc.n_instances == 0;
+    std::string err = prepare_scene<R>(desc, max_leaf, threads, sc.host, on_device ? PREP_TABLES : PREP_ALL);
     if (!err.empty()) return fail(TAKE_E_INVALID, err);
+    clock.lap(on_device ? "host validation + tables" : "host records + SAH build");
     HostScene<R> &h = sc.host;
-    HIP_TRY(sc.prims.upload(h.prims));
     bool use_q = false;
     if (on_device) {
-        const int rc = build_bvh_device_any<R>(sc, max_leaf, sc.group == 2 && fmt != "wide", fmt == "q16");
+        int rc = TAKE_OK;
+        if constexpr (sizeof(R) == 4) {
+            rc = make_prims_on_device(sc, desc);
+            clock.lap("mesh arrays -> HBM, records");
+            if (!rc) rc = build_bvh_device(sc, max_leaf, sc.group == 2 && fmt != "wide", fmt == "q16");
+        } else {
+            rc = 1;
+        }
         if (rc == 1) {  // not buildable on the device (tree too deep): do it on the host after all
             on_device = false;
-            err = prepare_scene<R>(desc, max_leaf, threads, sc.host, true);
+            err = prepare_scene<R>(desc, max_leaf, threads, sc.host, PREP_ALL);
             if (!err.empty()) return fail(TAKE_E_INVALID, err);
-            HIP_TRY(sc.prims.upload(h.prims));
-                } else if (rc != TAKE_OK) {
+        } else if (rc != TAKE_OK) {
             return rc;
         } else {
             use_q = sc.qnodes.p != nullptr;
         }
+    }
+    if (!on_device) {
+        HIP_TRY(sc.prims.upload(h.prims));
+        clock.lap("primitive records -> HBM");
     }
     if (!on_device) {
         use_q = sc.group == 2 && !h.qnodes.empty();  // compressed nodes: f32 pair kernel
@@ -324,6 +404,7 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
         else HIP_TRY(sc.nodes.upload(h.nodes));
     }
     sc.built_on_device = on_device;
+    clock.lap(on_device ? "device LBVH build" : "nodes -> HBM");
     // the trace kernels address nodes and primitive records with 32-bit byte offsets (full-rate integer math)
     {
         const uint64_t node_bytes = (uint64_t)h.stats.n_nodes * (use_q ? sizeof(QNode4) : sizeof(Node4<R>));
@@ -332,9 +413,9 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
             return fail(TAKE_E_INVALID, "scene too large for the 32-bit record offsets of the trace kernels (" +
                                             std::to_string(sc.prims.n) + " primitives, " + std::to_string(h.stats.n_nodes) + " nodes)");
     }
-    HIP_TRY(sc.shapes.upload(h.shapes));
+    // (ShapeInfo stays on the host: every kernel reads the shading side of a primitive from its own record)
     HIP_TRY(sc.meshes.upload(h.meshes));
-    HIP_TRY(sc.face_idx.upload(h.face_idx));
+    if (!on_device) HIP_TRY(sc.face_idx.upload(h.face_idx));  // (device build: already there, k_make_prims read it)
     HIP_TRY(sc.normals.upload(h.normals));
     HIP_TRY(sc.uvs.upload(h.uvs));
     HIP_TRY(sc.texels.upload(h.texels));
@@ -355,7 +436,7 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     d.nodes = sc.nodes.p;
     d.qnodes = use_q ? sc.qnodes.p : nullptr;
     d.prims = sc.prims.p;
-    d.shapes = sc.shapes.p;
+    d.shapes = nullptr;
     d.meshes = sc.meshes.p;
     d.face_idx = sc.face_idx.p;
     d.normals = sc.normals.p;
@@ -389,6 +470,7 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     sc.trace_grid = ts->num_cus * per_cu;
     sc.spill_stride = (int64_t)sc.trace_grid * groups_per_block;
     HIP_TRY(sc.spill.alloc((size_t)sc.spill_stride * spill_levels));
+    clock.lap("shading tables -> HBM, grid");
     return TAKE_OK;
 }
 
@@ -844,6 +926,7 @@ int take_hip_scene_create(const TakeSceneDesc *desc, const TakeBuildOpts *opts, 
     if (opts) o = *opts;
     if (o.precision != TAKE_PRECISION_F32 && o.precision != TAKE_PRECISION_F64)
         return fail(TAKE_E_INVALID, "unknown precision");
+    if (o.builder < TAKE_BUILDER_AUTO || o.builder > TAKE_BUILDER_HOST_SAH) return fail(TAKE_E_INVALID, "unknown builder");
     TakeScene *ts = new (std::nothrow) TakeScene();
     if (!ts) return fail(TAKE_E_NOMEM, "out of host memory");
     ts->precision = o.precision;
@@ -919,6 +1002,43 @@ int take_hip_render(TakeScene *ts, const TakeRenderOpts *opts, void *rgb_out_hos
         if (!rc) rc = render_impl<float>(ts, *opts, ts->f.out.p, nullptr);
         if (!rc) HIP_TRY(hipMemcpy(rgb_out_host, ts->f.out.p, bytes, hipMemcpyDeviceToHost));
     }
+    return rc;
+}
+
+int take_hip_pack_exr_scanlines(const void *d_rgb, int32_t precision, int32_t width, int32_t height, uint16_t *d_out, void *stream) {
+    if (!d_rgb || !d_out || width <= 0 || height <= 0) return fail(TAKE_E_INVALID, "bad argument");
+    if (precision != TAKE_PRECISION_F32 && precision != TAKE_PRECISION_F64) return fail(TAKE_E_INVALID, "unknown precision");
+    const int nd = check_device();
+    if (nd < 0) return nd;
+    const int64_t total = (int64_t)width * height * 3;
+    const dim3 grid((unsigned)std::min<int64_t>((total + BLOCK - 1) / BLOCK, 8192));
+    if (precision == TAKE_PRECISION_F64)
+        hipLaunchKernelGGL((k_pack_exr<double>), grid, dim3(BLOCK), 0, (hipStream_t)stream, (const double *)d_rgb, width, height, d_out);
+    else
+        hipLaunchKernelGGL((k_pack_exr<float>), grid, dim3(BLOCK), 0, (hipStream_t)stream, (const float *)d_rgb, width, height, d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return TAKE_OK;
+}
+
+int take_hip_render_exr_scanlines(TakeScene *ts, const TakeRenderOpts *opts, uint16_t *out_host) {
+    if (!ts || !opts || !out_host) return fail(TAKE_E_INVALID, "null argument");
+    TAKE_ON_DEVICE(ts);
+    const bool f64 = ts->precision == TAKE_PRECISION_F64;
+    const int W = f64 ? ts->d.host.cam.width : ts->f.host.cam.width, H = f64 ? ts->d.host.cam.height : ts->f.host.cam.height;
+    TakeRenderOpts o = *opts;
+    o.strip_first = 0, o.strip_stride = 1;
+    int rc = f64 ? ensure_workspace(ts->d, 0, (int64_t)W * H) : ensure_workspace(ts->f, 0, (int64_t)W * H);
+    if (rc) return rc;
+    void *d_img = f64 ? (void *)ts->d.out.p : (void *)ts->f.out.p;
+    rc = f64 ? render_impl<double>(ts, o, d_img, nullptr) : render_impl<float>(ts, o, d_img, nullptr);
+    if (rc) return rc;
+    DevBuf<uint16_t> halves;
+    if (halves.alloc((size_t)W * H * 3) != hipSuccess) return fail(TAKE_E_NOMEM, "out of device memory for the scanline buffer");
+    rc = take_hip_pack_exr_scanlines(d_img, ts->precision, W, H, halves.p, nullptr);
+    if (!rc && hipMemcpy(out_host, halves.p, halves.bytes(), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(TAKE_E_DEVICE, "scanline download failed");
+    halves.release();
     return rc;
 }
 

@@ -69,6 +69,51 @@ __device__ __forceinline__ float half_area(const Box &b) {
     return x * y + y * z + z * x;
 }
 
+// ---- primitive records straight from the caller's mesh arrays (parser -> device buffers).
+// The same arithmetic as the host loop of tk_host_scene.h (positions rounded to float, e_k = v_k - v0 in float, no
+// contraction), so the records — and with them every hit — are bit-identical to the host-built ones.
+struct MeshSrc {
+    int64_t pos_off;   // first vertex of this mesh in the concatenated double positions (units: vertices)
+    int32_t fbase;     // first face in face_idx (units: faces)
+    int32_t material;
+    int32_t tag;       // material tag
+    int32_t has_attr;  // vertex normals and/or uvs exist
+};
+struct SphereSrc {
+    double c[3], r;
+    int32_t material, tag;
+};
+__global__ void __launch_bounds__(BLK)
+k_make_prims(const int32_t *__restrict__ kind, const int32_t *__restrict__ ref, const int32_t *__restrict__ face,
+             const int32_t *__restrict__ area_light, const MeshSrc *__restrict__ meshes, const double *__restrict__ positions,
+             const int32_t *__restrict__ face_idx, const SphereSrc *__restrict__ spheres, int n, PrimRec<float> *out) {
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    PrimRec<float> p{};
+    p.shape_id = i;
+    p.area_light = area_light[i];
+    p.nidx = -1;
+    if (kind[i] == 0) {
+        const SphereSrc s = spheres[ref[i]];
+        p.a[0] = (float)s.c[0], p.a[1] = (float)s.c[1], p.a[2] = (float)s.c[2], p.a[3] = (float)s.r;
+        p.meta = PRIM_SPHERE | (s.tag << 8);
+        p.material = s.material;
+        p.mesh = -(1 + ref[i]);
+    } else {
+        const MeshSrc m = meshes[ref[i]];
+        const int32_t *idx = face_idx + 3 * ((int64_t)m.fbase + face[i]);
+        float v[3][3];
+        for (int k = 0; k < 3; k++)
+            for (int a = 0; a < 3; a++) v[k][a] = (float)positions[3 * (m.pos_off + idx[k]) + a];
+        for (int a = 0; a < 3; a++) p.a[a] = v[0][a], p.a[3 + a] = v[1][a] - v[0][a], p.a[6 + a] = v[2][a] - v[0][a];
+        p.meta = PRIM_TRIANGLE | (m.tag << 8);
+        p.material = m.material;
+        p.mesh = ref[i];
+        if (m.has_attr) p.nidx = m.fbase + face[i], p.meta |= META_HAS_ATTR;
+    }
+    out[i] = p;
+}
+
 // scene_ord[0..2] = min of lo (ordered ints), [3..5] = max of hi; initialised to INT_MAX / INT_MIN by the caller
 __global__ void __launch_bounds__(BLK) k_prim_boxes(const PrimRec<float> *__restrict__ prims, int n, Box *pb, int *scene_ord) {
     const int i = blockIdx.x * BLK + threadIdx.x;

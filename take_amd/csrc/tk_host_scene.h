@@ -152,8 +152,15 @@ inline bool env_tables(const double *rgb, int w, int h, std::vector<double> &mar
     return true;
 }
 
+// what prepare_scene leaves to the device (TAKE_BUILDER_DEVICE_LBVH): PREP_ALL = nothing (records, host SAH tree);
+// PREP_RECORDS = the tree (records in shape order); PREP_TABLES = the tree AND the primitive records (made by
+// tk_build_gpu.h::k_make_prims straight from the caller's mesh arrays: at 10M triangles the host loop that writes
+// 640 MB of records was 470 of the 570 ms of scene_create) — only validation and the small tables happen here.
+enum PrepMode { PREP_ALL = 0, PREP_RECORDS = 1, PREP_TABLES = 2 };
 template <class R>
-std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, HostScene<R> &hs, bool build_bvh = true) {
+std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, HostScene<R> &hs, int mode = PREP_ALL) {
+    const bool build_bvh = mode == PREP_ALL;
+    const bool host_records = mode != PREP_TABLES;
     if (d.camera.width <= 0 || d.camera.height <= 0) return "camera width/height must be positive";
     if (d.n_shapes < 0 || d.n_meshes < 0 || d.n_spheres < 0 || d.n_lights < 0 || d.n_materials < 0 || d.n_images < 0)
         return "negative count in scene description";
@@ -186,11 +193,15 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
     for (int i = 0; i < d.n_meshes; i++) {
         const TakeMesh &m = d.meshes[i];
         const MeshInfo &mi = hs.meshes[i];
-        for (int64_t k = 0; k < 3 * m.n_faces; k++) {
-            const int32_t vi = m.indices[k];
-            if (vi < 0 || vi >= m.n_vertices) return "mesh " + std::to_string(i) + ": vertex index out of range";
-            hs.face_idx[3 * (size_t)mi.fbase + k] = vi;
-        }
+        const std::string ierr = for_chunks(3 * m.n_faces, threads, [&](int64_t k0, int64_t k1) -> std::string {
+            for (int64_t k = k0; k < k1; k++) {
+                const int32_t vi = m.indices[k];
+                if (vi < 0 || vi >= m.n_vertices) return "mesh " + std::to_string(i) + ": vertex index out of range";
+                hs.face_idx[3 * (size_t)mi.fbase + k] = vi;
+            }
+            return "";
+        });
+        if (!ierr.empty()) return ierr;
         if (m.normals)
             for (int64_t k = 0; k < 3 * m.n_vertices; k++) hs.normals[3 * (size_t)mi.nbase + k] = R(m.normals[k]);
         if (m.uvs)
@@ -240,11 +251,28 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
 
     // shapes -> primitive records (shape order for now) + build boxes
     const int64_t ns = d.n_shapes;
-    hs.shapes.resize(ns);
-    std::vector<PrimRec<R>> recs(ns);
-    std::vector<BuildPrim> bp(ns);
+    hs.shapes.clear();
+    if (host_records) hs.shapes.resize(ns);
+    std::vector<PrimRec<R>> recs(host_records ? ns : 0);
+    std::vector<BuildPrim> bp(build_bvh ? ns : 0);
     std::string shape_err = for_chunks(ns, threads, [&](int64_t i_begin, int64_t i_end) -> std::string {
     for (int64_t i = i_begin; i < i_end; i++) {
+        if (!host_records) {  // validation only: the records are made on the device
+            const int32_t al = d.shape_area_light[i];
+            if (al < -1 || al >= d.n_lights) return "shape " + std::to_string(i) + ": bad area_light id";
+            if (d.shape_kind[i] == 0) {
+                const int32_t si = d.shape_ref[i];
+                if (si < 0 || si >= d.n_spheres) return "shape " + std::to_string(i) + ": bad sphere index";
+                if (d.spheres[si].material_id < 0 || d.spheres[si].material_id >= d.n_materials) return "sphere: bad material id";
+            } else if (d.shape_kind[i] == 1) {
+                const int32_t mi = d.shape_ref[i], fi = d.shape_face[i];
+                if (mi < 0 || mi >= d.n_meshes) return "shape " + std::to_string(i) + ": bad mesh index";
+                if (fi < 0 || fi >= d.meshes[mi].n_faces) return "shape " + std::to_string(i) + ": bad face index";
+            } else {
+                return "shape " + std::to_string(i) + ": unknown kind";
+            }
+            continue;
+        }
         PrimRec<R> &p = recs[i];
         p = PrimRec<R>{};
         p.shape_id = (int32_t)i;
@@ -260,6 +288,7 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
             for (int a = 0; a < 3; a++) p.a[a] = R(s.center[a]);
             p.a[3] = R(s.radius);
             hs.shapes[i] = ShapeInfo{-(1 + si), 0, material, al};
+            if (build_bvh)
             for (int a = 0; a < 3; a++) {  // bounds of src/scene.cpp:8-10, from the R-typed values
                 bp[i].bmin[a] = (double)(p.a[a] - p.a[3]);
                 bp[i].bmax[a] = (double)(p.a[a] + p.a[3]);
@@ -284,6 +313,7 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
             p.a[3] = e1.x, p.a[4] = e1.y, p.a[5] = e1.z;
             p.a[6] = e2.x, p.a[7] = e2.y, p.a[8] = e2.z;
             hs.shapes[i] = ShapeInfo{mi, fi, material, al};
+            if (build_bvh)
             for (int a = 0; a < 3; a++) {
                 const double x0 = (double)(&v[0].x)[a], x1 = (double)(&v[1].x)[a], x2 = (double)(&v[2].x)[a];
                 bp[i].bmin[a] = std::min(x0, std::min(x1, x2));
@@ -294,7 +324,7 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
             return "shape " + std::to_string(i) + ": unknown kind";
         }
         p.meta |= hs.materials[material].tag << 8;
-        bp[i].id = (int32_t)i;
+        if (build_bvh) bp[i].id = (int32_t)i;
     }
     return "";
     });
@@ -348,10 +378,14 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
         if (l.kind != 1) return "light " + std::to_string(i) + ": unknown kind";
         if (l.shape_id < 0 || l.shape_id >= ns) return "light " + std::to_string(i) + ": bad shape id";
         o.shape_id = l.shape_id;
-        const ShapeInfo &si = hs.shapes[l.shape_id];
+        // (read from the description, not from the records: in PREP_TABLES mode there are none on the host)
+        const ShapeInfo si = d.shape_kind[l.shape_id] == 0 ? ShapeInfo{-(1 + d.shape_ref[l.shape_id]), 0, 0, 0}
+                                                            : ShapeInfo{d.shape_ref[l.shape_id], d.shape_face[l.shape_id], 0, 0};
         if (si.mesh < 0) {
             o.is_sphere = 1;
-            for (int a = 0; a < 4; a++) o.v[a] = recs[l.shape_id].a[a];
+            const TakeSphere &sp = d.spheres[-si.mesh - 1];
+            for (int a = 0; a < 3; a++) o.v[a] = R(sp.center[a]);
+            o.v[3] = R(sp.radius);
         } else {
             const TakeMesh &m = d.meshes[si.mesh];
             // the reference reads mesh.normals.at() when sampling a triangle light and throws on an emissive
@@ -400,7 +434,7 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
     // order — tk_build_gpu.h — and only the records are prepared here)
     std::vector<int32_t> order;
     if (!build_bvh) {
-        order.resize(bp.size());
+        order.resize((size_t)ns);
         for (size_t k = 0; k < order.size(); k++) order[k] = (int32_t)k;
         hs.nodes.clear();
         hs.qnodes.clear();
@@ -589,10 +623,14 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
         for (size_t k = 0; k < blas.size(); k++)
             std::copy(blas[k].prims.begin(), blas[k].prims.end(), hs.prims.begin() + blas_prim_base[k]);
     }
+    if (!host_records) {
+        hs.prims.clear();
+        return "";
+    }
     if (hs.prims.size() < order.size()) hs.prims.resize(order.size());  // (two-level scenes: the prototypes' records follow)
     for_chunks((int64_t)order.size(), threads, [&](int64_t k_begin, int64_t k_end) -> std::string {
     for (int64_t k = k_begin; k < k_end; k++) {
-        hs.prims[k] = recs[bp[order[k]].id];
+        hs.prims[k] = recs[build_bvh ? bp[order[k]].id : order[k]];
         const ShapeInfo &si = hs.shapes[hs.prims[k].shape_id];
         PrimRec<R> &pr = hs.prims[k];
         pr.material = si.material, pr.area_light = si.area_light, pr.nidx = -1, pr.mesh = si.mesh;

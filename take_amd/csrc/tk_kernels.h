@@ -239,6 +239,42 @@ k_resolve(const R *__restrict__ accum, R *out, int32_t width, int32_t n_local_ro
     }
 }
 
+// ---- egress on the device: the conversion half of the reference's imwrite("image.exr")
+// (src/image.cpp:155-176: Image3 double -> float, then tinyexr's SaveEXR(.., components 3, fp16) -> per scanline the
+// channels B, G, R as 16-bit halves).  One thread per pixel and channel; out = uint16 [height][3][width] in the byte
+// order of an EXR scanline block before its ZIP pre-filter, so that the host only has to deflate and frame it.
+// float -> half as that writer rounds (pinned on files it wrote, tests/golden/egress): the magnitude is rounded
+// HALF UP on the first dropped mantissa bit — not to nearest-even; a carry may run into the exponent (up to inf);
+// float denormals become zero; anything at or beyond 2^16 becomes inf; below the half normal range the same rule
+// produces half denormals.
+__device__ __forceinline__ uint16_t exr_half_bits(float f) {
+    const uint32_t u = __float_as_uint(f);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const int32_t exp = (int32_t)((u >> 23) & 0xFFu);
+    const uint32_t man = u & 0x7FFFFFu;
+    const int32_t newexp = exp - 112;
+    uint32_t out = 0;
+    if (exp == 255) out = 0x7C00u | (man != 0 ? 0x200u : 0u);
+    else if (exp != 0 && newexp >= 31) out = 0x7C00u;
+    else if (exp != 0 && newexp > 0) out = (((uint32_t)newexp << 10) | (man >> 13)) + ((man >> 12) & 1u);
+    else if (exp != 0 && 14 - newexp <= 24) {
+        const uint32_t full = man | 0x800000u;
+        const int sh = 14 - newexp;
+        out = (full >> sh) + ((full >> (sh - 1)) & 1u);
+    }
+    return (uint16_t)(out | sign);
+}
+template <class R>
+__global__ void __launch_bounds__(BLOCK) k_pack_exr(const R *__restrict__ rgb, int32_t width, int32_t height, uint16_t *out) {
+    const int64_t total = (int64_t)width * height * 3;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
+        const int x = (int)(i % width);
+        const int c = (int)((i / width) % 3);  // position in the scanline: 0 = B, 1 = G, 2 = R
+        const int64_t y = i / ((int64_t)3 * width);
+        out[i] = exr_half_bits((float)rgb[(y * width + x) * 3 + (2 - c)]);
+    }
+}
+
 }  // namespace tk
 
 // ---- take_hip_debug_table: the device shading functions on the rows of the reference's golden tables

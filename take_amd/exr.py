@@ -66,8 +66,17 @@ def write_exr(path, img):
     """img: (H, W, 3) RGB float array in Image3 order (row 0 = top).  Writes what the reference's imwrite writes."""
     a = np.asarray(img, np.float32)
     assert a.ndim == 3 and a.shape[2] == 3
-    h, w = a.shape[:2]
-    half = float_to_half(a).view(np.float16)
+    half = float_to_half(a)  # (H, W, 3) bit patterns
+    write_exr_scanlines(path, np.ascontiguousarray(half[:, :, ::-1].transpose(0, 2, 1)))  # per line: B, G, R
+
+
+def write_exr_scanlines(path, scan):
+    """scan: uint16 (H, 3, W) — per scanline the B, G, R half bit patterns, i.e. what libtake_hip's device-side
+    egress (take_hip_pack_exr_scanlines / Scene.render_exr_scanlines) hands over.  What is left for the host is the
+    byte-serial part of the reference's imwrite: ZIP pre-filter + deflate per 16-line block, header, offset table."""
+    scan = np.ascontiguousarray(scan, np.uint16)
+    assert scan.ndim == 3 and scan.shape[1] == 3
+    h, w = scan.shape[0], scan.shape[2]
     comp = COMPRESSION["none"] if (w < 16 and h < 16) else COMPRESSION["zip"]
     chlist = b"".join(n + b"\0" + struct.pack("<iBBBBii", 1, 0, 0, 0, 0, 1, 1) for n in (b"B", b"G", b"R")) + b"\0"
     box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
@@ -84,8 +93,7 @@ def write_exr(path, img):
     lines = LINES_PER_BLOCK[comp]
     chunks = []
     for y0 in range(0, h, lines):
-        rows = half[y0:y0 + lines]  # (n, W, 3)
-        raw = b"".join(rows[r, :, c].tobytes() for r in range(rows.shape[0]) for c in (2, 1, 0))  # per line: B, G, R
+        raw = scan[y0:y0 + lines].astype("<u2").tobytes()
         data = raw
         if comp != 0:
             z = zlib.compress(_predict(raw))

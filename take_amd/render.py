@@ -72,9 +72,19 @@ def main(argv=None):
     if "-t" in params:  # main.cpp:13-15: thread count of the CPU pool; meaningless here, accepted and dropped
         i = params.index("-t")
         del params[i:i + 2]
-    img = render(params)
-    if img.size:
-        imwrite("image.exr", img)
+    if not params:
+        return 0  # an empty image is not written (src/image.cpp:136-138)
+    # render + float -> half + scanline packing on the device (take_hip_render_exr_scanlines); what the host adds is
+    # the byte-serial rest of imwrite: ZIP pre-filter, deflate, header (take_amd/exr.py)
+    from .exr import write_exr_scanlines
+
+    filename, max_depth = parse_params(params)
+    sd = load_tkscene(filename)
+    scene = Scene(sd)
+    try:
+        write_exr_scanlines("image.exr", scene.render_exr_scanlines(spp=sd.spp, max_depth=max_depth, seed=0))
+    finally:
+        scene.close()
     return 0
 
 

@@ -59,3 +59,56 @@ def test_roundtrip_of_a_large_random_image(tmp_path):
     # apart from ties the conversion agrees with IEEE round-to-nearest
     with np.errstate(over="ignore"):
         assert np.mean(ch["G"].view(np.uint16) == img.astype(np.float32).astype(np.float16)[..., 1].view(np.uint16)) > 0.999
+
+
+# ------------------------------------------------------------------ device-side egress
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("precision", [0, 1])
+def test_device_packs_the_scanlines_the_reference_writer_stores(name, precision, tmp_path):
+    """take_hip_pack_exr_scanlines on the golden float images == the halves inside the EXR files the reference's own
+    imwrite made of them, bit for bit (ties, overflow to inf, denormals included); framed by write_exr_scanlines the
+    result is the file our host writer produces."""
+    import ctypes as C
+
+    import torch
+
+    from take_amd import capi
+    from take_amd.exr import write_exr_scanlines
+
+    img = load(name)
+    h, w = img.shape[:2]
+    dev = torch.tensor(img, dtype=torch.float64 if precision else torch.float32, device="cuda")
+    out = torch.zeros((h, 3, w), dtype=torch.int16, device="cuda")
+    rc = capi.lib().take_hip_pack_exr_scanlines(C.c_void_p(dev.data_ptr()), precision, w, h, C.c_void_p(out.data_ptr()), None)
+    assert rc == 0
+    scan = out.cpu().numpy().view(np.uint16)
+    ref, _ = read_exr(os.path.join(GOLD, "egress", name + ".exr"))
+    for k, c in enumerate(("B", "G", "R")):
+        assert np.array_equal(scan[:, k, :], ref[c].view(np.uint16)), c
+    a, b = str(tmp_path / "dev.exr"), str(tmp_path / "host.exr")
+    write_exr_scanlines(a, scan)
+    write_exr(b, img)
+    assert open(a, "rb").read() == open(b, "rb").read()
+
+
+@pytest.mark.gpu
+def test_render_to_exr_scanlines_on_the_device(tmp_path):
+    from helpers import golden_scene
+    from take_amd import capi
+    from take_amd.exr import write_exr_scanlines
+
+    sd = golden_scene("cbox")
+    sc = capi.Scene(sd)
+    try:
+        img = sc.render(spp=4, max_depth=5, seed=2)
+        scan = sc.render_exr_scanlines(spp=4, max_depth=5, seed=2)
+    finally:
+        sc.close()
+    want = float_to_half(img)  # (H, W, 3) R G B
+    for k, c in enumerate((2, 1, 0)):
+        assert np.array_equal(scan[:, k, :], want[:, :, c])
+    a, b = str(tmp_path / "dev.exr"), str(tmp_path / "host.exr")
+    write_exr_scanlines(a, scan)
+    write_exr(b, img)
+    assert open(a, "rb").read() == open(b, "rb").read()
