@@ -293,6 +293,52 @@ int main(int argc, char **argv) {
         }
         std::printf("  GPU-order any-hit (slot mode %d): nodes %.2f leaves %.2f per ray\n", mode, (double)un / nr, (double)ul / nr);
     }
+    if (std::getenv("LAB_ANYORDER")) {
+        for (int mode = 0; mode < 5; mode++) {
+            std::mt19937_64 r(99);
+            std::uniform_real_distribution<float> V(-1.f, 1.f);
+            uint64_t un = 0, ul = 0, occ = 0; int nr = 0;
+            for (int i = 0; i < n_rays; i += 4, nr++) {
+                const int k = (int)(r() % (uint64_t)nt);
+                const float *p = &tri[9 * k];
+                float o[3];
+                for (int a = 0; a < 3; a++) o[a] = (p[a] + p[3 + a] + p[6 + a]) / 3.f;
+                const float lx = 0.3f * V(r), lz = 0.3f * V(r), ly = 0.99f;
+                float dd[3] = {lx - o[0], ly - o[1], lz - o[2]};
+                const float dist = std::sqrt(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]);
+                RayT<float> ray = make_ray(o[0], o[1], o[2], dd[0] / dist, dd[1] / dist, dd[2] / dist, 1e-4f, (1.f - 1e-4f) * dist);
+                const float idx = safe_inv(ray.d.x), idy = safe_inv(ray.d.y), idz = safe_inv(ray.d.z);
+                int32_t stk[256]; int sp = 0; int32_t cur = root_child; bool found = false;
+                for (;;) {
+                    if (cur >= 0) {
+                        un++;
+                        int32_t hc[4]; float hk[4]; int nh = 0;
+                        for (int j = 0; j < 4; j++) {
+                            const NodeChild<float> &c = nodes[cur].c[j];
+                            float tn;
+                            if (!box_test(c, ray.o, idx, idy, idz, ray.tmin, ray.tmax, tn)) continue;
+                            // exit distance
+                            float t0x = (c.bmin[0] - ray.o.x) * idx, t1x = (c.bmax[0] - ray.o.x) * idx, t0y = (c.bmin[1] - ray.o.y) * idy, t1y = (c.bmax[1] - ray.o.y) * idy;
+                            float t0z = (c.bmin[2] - ray.o.z) * idz, t1z = (c.bmax[2] - ray.o.z) * idz;
+                            float tf = std::min(std::min(std::max(t0x, t1x), std::max(t0y, t1y)), std::min(std::max(t0z, t1z), ray.tmax));
+                            float key = mode == 0 ? (float)j : mode == 1 ? -(tf - tn) : mode == 2 ? tn : mode == 3 ? -tn : -(tf - tn) / (1e-6f + (c.bmax[0]-c.bmin[0]) + (c.bmax[1]-c.bmin[1]) + (c.bmax[2]-c.bmin[2]));
+                            hc[nh] = c.child, hk[nh] = key, nh++;
+                        }
+                        for (int a2 = 0; a2 < nh; a2++) for (int b2 = a2 + 1; b2 < nh; b2++) if (hk[b2] < hk[a2]) std::swap(hk[a2], hk[b2]), std::swap(hc[a2], hc[b2]);
+                        if (nh) { for (int j = nh - 1; j >= 1; j--) stk[sp++] = hc[j]; cur = hc[0]; continue; }
+                    } else if (cur != CHILD_EMPTY) {
+                        ul++;
+                        const int first = leaf_first(cur), cnt = leaf_count(cur);
+                        for (int q = 0; q < cnt; q++) { float t, u, v; if (tri_test(prims[first + q].a, ray, ray.tmax, t, u, v)) found = true; }
+                        if (found) { occ++; break; }
+                    }
+                    if (sp == 0) break;
+                    cur = stk[--sp];
+                }
+            }
+            std::printf("  light rays, any-hit order mode %d: nodes %.2f leaves %.2f per ray (occluded %.1f%%)\n", mode, (double)un / nr, (double)ul / nr, 100.0 * occ / nr);
+        }
+    }
     uint64_t a = 0, b = 0, c = 0, d = 0, h = 0, e = 0, f = 0;
     for (int t = 0; t < T; t++) a += cn[t], b += cp[t], c += sn[t], d += sp[t], h += hits[t], e += cl[t], f += sl[t];
     const double N = n_rays;

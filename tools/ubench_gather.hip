@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <string>
 #include <vector>
 
 #define CK(x)                                                                      \
@@ -77,7 +78,23 @@ int run(const uint4* d_table, size_t table_bytes, uint32_t* d_out, int waves_per
     return 0;
 }
 
-int main() {
+// `ubench_gather calib`: the FETCH_SIZE calibration VERDICT r1 asked for.  Dependent random gathers of the trace
+// kernel's shape (a pair reads a 64-byte record with 2 x dwordx4 per lane; and the 128-byte variant, 4 per lane) from
+// a 1 GiB table — 32x the L2s and 4x the Infinity Cache, so all but ~3 % of the fetches leave the L2.  The byte count
+// is known (printed); run under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and divide (tools/calibrate_fetch.sh).
+template <int G, int NODE> int calib(const uint4* d_table, uint32_t* d_out, const char* name) {
+    const uint32_t n_nodes = (uint32_t)(((size_t)1 << 30) / NODE);
+    const uint32_t mask = n_nodes - 1;  // a power of two
+    const int blocks = 256 * 6, iters = 4000;
+    k_gather<G, NODE><<<blocks, 256>>>(d_table, mask, iters, d_out);
+    CK(hipDeviceSynchronize());
+    const double fetches = (double)blocks * 256 / G * iters;
+    printf("CALIB %s fetches %.0f record_bytes %d requested_bytes %.0f lines128_bytes %.0f\n", name, fetches, NODE, fetches * NODE,
+           fetches * 128.0);
+    return 0;
+}
+
+int main(int argc, char** argv) {
     const size_t max_bytes = (size_t)1 << 30;
     uint4* d_table;
     uint32_t* d_out;
@@ -90,6 +107,11 @@ int main() {
         w = s >> 8;
     }
     CK(hipMemcpy(d_table, h.data(), max_bytes, hipMemcpyHostToDevice));
+    if (argc > 1 && std::string(argv[1]) == "calib") {
+        if (calib<2, 64>(d_table, d_out, "pair_64B")) return 1;
+        if (calib<2, 128>(d_table, d_out, "pair_128B")) return 1;
+        return 0;
+    }
     const size_t sizes[] = {16u << 10, 2u << 20, 32u << 20, 128u << 20, 1u << 30};
     for (size_t sz : sizes) {
         for (int w : {6, 8}) {
