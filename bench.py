@@ -69,6 +69,9 @@ def parse_args():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3],
                     help="BASELINE.json configs index: 2 = 1920x1080x256 spp per GPU (weak scaling, default); 3 = 4096x4096, "
                          "1024 spp total, rows sharded over the ranks (strong scaling)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64"],
+                    help="arithmetic of the timed steps: f32 = production (default); f64 = the reference's Real (profiling "
+                         "the reference-precision path on its own; implies --f64-steps 0)")
     ap.add_argument("--f64-steps", type=int, default=2,
                     help="timed steps of the same workload on the f64 (reference-precision) device path, N = 1 only; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -76,6 +79,8 @@ def parse_args():
     args = ap.parse_args()
     if args.config == 3:
         args.width, args.height, args.spp = 4096, 4096, 1024
+    if args.precision == "f64":
+        args.f64_steps = 0
     return args
 
 
@@ -250,12 +255,13 @@ def main():
     else:
         sd = scenes.soup_scene(args.tris, args.width, args.height, spp=spp_total, max_depth=args.max_depth,
                                materials=args.materials, envmap=(2048, 1024) if args.envmap else None)
-    scene = capi.Scene(sd, precision=D.TAKE_PRECISION_F32, max_leaf_size=args.max_leaf,
+    f64_main = args.precision == "f64"
+    scene = capi.Scene(sd, precision=D.TAKE_PRECISION_F64 if f64_main else D.TAKE_PRECISION_F32, max_leaf_size=args.max_leaf,
                        builder={"device": D.TAKE_BUILDER_DEVICE_LBVH, "host": D.TAKE_BUILDER_HOST_SAH, "auto": D.TAKE_BUILDER_AUTO}[args.builder])
     t_setup = time.time() - t0
     stats = scene.stats()
     rows = strip_rows(args.height, rank, world)
-    out = torch.empty((len(rows), args.width, 3), dtype=torch.float32, device="cuda")
+    out = torch.empty((len(rows), args.width, 3), dtype=torch.float64 if f64_main else torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -269,7 +275,7 @@ def main():
     cc = scene.counters()
     rays_counted = cc["rays_closest"] + cc["rays_shadow"]
     bytes_per_ray = ((cc["node_visits"] * cc["node_bytes"] + cc["prim_tests"] * cc["prim_bytes"]) / max(rays_counted, 1)
-                     + STATE_BYTES_PER_RAY)
+                     + (2 * STATE_BYTES_PER_RAY - 4 if f64_main else STATE_BYTES_PER_RAY))
     scene.set_instrumentation(timing=True, counting=False)
 
     for _ in range(args.warmup):
@@ -309,7 +315,7 @@ def main():
             "metric": "Msamples/s (camera paths/s: rays traced x spp / s), 1M-tri soup",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": (f"{args.instanced} placements x triangles ({'flattened to world space' if args.flatten else 'two-level instancing'}, 7 BSDFs round-robin)" if args.instanced else
                                     f"procedural {args.tris}-triangle soup ({args.materials} materials)")
                                    + " in 5-wall box + 1 quad area light, "
@@ -331,7 +337,7 @@ def main():
                          "achieved_is": "algorithmic bytes (node_visits x node bytes + prim_tests x 48 B + ray state) per "
                                         "launch / launch time; mostly served by L2 / Infinity Cache — the kernel is "
                                         "VALU-issue-bound (DESIGN.md §7), `traffic` is what reaches the fabric",
-                         "kernel": "tk::k_trace_group<float,2,false,false,PathIo<float>,true> (closest hit, pair kernel, compressed nodes)", "launches": n_launch,
+                         "kernel": f"tk::k_trace_group<{'double' if f64_main else 'float'},2,false,false,PathIo<..>,true> (closest hit, pair kernel, compressed nodes)", "launches": n_launch,
                          "avg_launch_ms": avg_ms, "bytes_per_ray": bytes_per_ray,
                          "rays_per_launch": acc["rays_closest"] / n_launch},
         }

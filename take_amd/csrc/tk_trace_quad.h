@@ -28,6 +28,9 @@ namespace tk {
 #ifndef TQ_MIN_WAVES
 #define TQ_MIN_WAVES 6  // register cap for 6 waves per SIMD: measured +4 % on the pair kernel (7 and 8 spill and lose)
 #endif
+#ifndef TQ_F64_WAVES
+#define TQ_F64_WAVES 4  // register cap of the f64 instances (waves per SIMD)
+#endif
 #ifndef TQ_PAIR_LEVELS
 #define TQ_PAIR_LEVELS 24
 #endif
@@ -187,7 +190,7 @@ template <int G> __device__ __forceinline__ int group_max_i(int v) {
 // continues at the prototype's root; when the marker is popped the ray gets its world-space form back.  A separate
 // instance of the kernel, so that one-level scenes pay nothing.
 template <class R, int G, bool ANY_HIT, bool COUNT, class Io, bool QN = false, bool INST = false>
-__global__ void __launch_bounds__(TQ_BLOCK, sizeof(R) == 8 ? (INST ? 3 : 4) : (INST ? TQ_MIN_WAVES - 1 : TQ_MIN_WAVES))  // f64, two-level: room for the wider state
+__global__ void __launch_bounds__(TQ_BLOCK, sizeof(R) == 8 ? (INST ? TQ_F64_WAVES - 1 : TQ_F64_WAVES) : (INST ? TQ_MIN_WAVES - 1 : TQ_MIN_WAVES))  // f64, two-level: room for the wider state
 k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_t n_direct, int32_t *head,
               unsigned long long *counters, int counter_word, StackSpill spill) {
     using GG = GroupGeom<G>;
