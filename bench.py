@@ -46,9 +46,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tris", type=int, default=1_000_000)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=256, help="samples per pixel per GPU")
+    ap.add_argument("--width", type=int, default=None, help="default 1920 (config 2) / 4096 (config 3)")
+    ap.add_argument("--height", type=int, default=None, help="default 1080 / 4096")
+    ap.add_argument("--spp", type=int, default=None, help="samples per pixel: per GPU, default 256 (config 2); total, default 1024 (config 3)")
     ap.add_argument("--max-depth", type=int, default=50)
     ap.add_argument("--spb", type=int, default=0, help="samples per pixel per batch (0 = auto)")
     ap.add_argument("--materials", default="diffuse", choices=["diffuse", "mixed"],
@@ -77,8 +77,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="640x360x1", help="WxHxSPP of the CPU-baseline sample")
     args = ap.parse_args()
-    if args.config == 3:
-        args.width, args.height, args.spp = 4096, 4096, 1024
+    dw, dh, ds = (4096, 4096, 1024) if args.config == 3 else (1920, 1080, 256)
+    args.width = dw if args.width is None else args.width
+    args.height = dh if args.height is None else args.height
+    args.spp = ds if args.spp is None else args.spp
     if args.precision == "f64":
         args.f64_steps = 0
     return args

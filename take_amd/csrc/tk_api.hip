@@ -467,10 +467,15 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
         else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>, false, true>, TQ_BLOCK, 0));
     }
     per_cu = std::max(1, std::min(per_cu, 8));
+    if (const char *e = std::getenv("TAKE_HIP_TRACE_BLOCKS")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));  // experiment: leave room for a concurrent kernel
     sc.trace_grid = ts->num_cus * per_cu;
     sc.spill_stride = (int64_t)sc.trace_grid * groups_per_block;
     HIP_TRY(sc.spill.alloc((size_t)sc.spill_stride * spill_levels));
     clock.lap("shading tables -> HBM, grid");
+    // everything the kernels read is in HBM now; the host keeps the small tables (camera, material tags, tree
+    // statistics) and drops the copies of the large arrays (1.1 GB at 10M triangles)
+    h.nodes = {}, h.qnodes = {}, h.prims = {}, h.shapes = {}, h.face_idx = {}, h.normals = {}, h.uvs = {}, h.texels = {};
+    h.inst_trace = {}, h.inst_shade = {};
     return TAKE_OK;
 }
 
@@ -1121,6 +1126,66 @@ int take_hip_debug_table(int32_t kind, int32_t precision, const double *in, int6
 // ------------------------------------------------------------------------------------------------ scene groups
 }  // extern "C"
 
+namespace {
+// A replica of `src` on `device`: every device array is copied peer to peer (xGMI between the GPUs of a node), the
+// small host tables by value — the scene is prepared and its tree built ONCE per group, whichever builder made it.
+template <class T> int peer_copy(DevBuf<T> &dst, int dst_dev, const DevBuf<T> &src, int src_dev) {
+    if (dst.alloc(src.n) != hipSuccess) return fail(TAKE_E_NOMEM, "out of device memory for a scene replica");
+    if (src.n && hipMemcpyPeer(dst.p, dst_dev, src.p, src_dev, src.bytes()) != hipSuccess)
+        return fail(TAKE_E_DEVICE, "hipMemcpyPeer of a scene array failed");
+    return TAKE_OK;
+}
+template <class R> int replicate_t(const SceneT<R> &a, int a_dev, SceneT<R> &b, int b_dev) {
+    int rc = TAKE_OK;
+#define TK_COPY(member) if (!rc) rc = peer_copy(b.member, b_dev, a.member, a_dev)
+    TK_COPY(nodes); TK_COPY(qnodes); TK_COPY(prims); TK_COPY(meshes); TK_COPY(face_idx); TK_COPY(normals); TK_COPY(uvs);
+    TK_COPY(texels); TK_COPY(materials); TK_COPY(images); TK_COPY(lights); TK_COPY(light_pmf); TK_COPY(light_cdf);
+    TK_COPY(inst_trace); TK_COPY(inst_shade); TK_COPY(env_marginal); TK_COPY(env_conditional); TK_COPY(env_guide_m);
+    TK_COPY(env_guide_c);
+#undef TK_COPY
+    if (rc) return rc;
+    // small host tables (the large vectors were dropped after the upload)
+    b.host.cam = a.host.cam;
+    b.host.env = a.host.env;
+    b.host.stats = a.host.stats;
+    b.host.n_material_tags = a.host.n_material_tags, b.host.tag_mask = a.host.tag_mask, b.host.single_tag = a.host.single_tag;
+    b.host.q_inflation = a.host.q_inflation, b.host.root_child = a.host.root_child;
+    b.host.n_blas = a.host.n_blas, b.host.blas_nodes = a.host.blas_nodes, b.host.blas_prims = a.host.blas_prims;
+    for (int k = 0; k < 3; k++) b.host.grid_lo[k] = a.host.grid_lo[k], b.host.grid_step[k] = a.host.grid_step[k], b.host.background[k] = a.host.background[k];
+    DeviceScene<R> &d = b.dev;
+    d = a.dev;  // the plain values; then the pointers of this device
+    d.nodes = b.nodes.p, d.qnodes = a.dev.qnodes ? b.qnodes.p : nullptr, d.prims = b.prims.p, d.shapes = nullptr;
+    d.meshes = b.meshes.p, d.face_idx = b.face_idx.p, d.normals = b.normals.p, d.uvs = b.uvs.p, d.texels = b.texels.p;
+    d.materials = b.materials.p, d.images = b.images.p, d.lights = b.lights.p, d.light_pmf = b.light_pmf.p, d.light_cdf = b.light_cdf.p;
+    d.inst_trace = b.inst_trace.p, d.inst_shade = b.inst_shade.p;
+    d.env.marginal = b.env_marginal.p, d.env.conditional = b.env_conditional.p, d.env.guide_m = b.env_guide_m.p, d.env.guide_c = b.env_guide_c.p;
+    b.group = a.group, b.built_on_device = a.built_on_device, b.trace_grid = a.trace_grid, b.spill_stride = a.spill_stride;
+    if (b.qwords.alloc(a.qwords.n) != hipSuccess || b.counters.alloc(a.counters.n) != hipSuccess || b.spill.alloc(a.spill.n) != hipSuccess)
+        return fail(TAKE_E_NOMEM, "out of device memory for a scene replica");
+    HIP_TRY(hipMemset(b.qwords.p, 0, b.qwords.bytes()));
+    HIP_TRY(hipMemset(b.counters.p, 0, b.counters.bytes()));
+    return TAKE_OK;
+}
+// -> a new scene handle on `device` (made current for the call), equal to `src`
+int replicate_scene(const TakeScene *src, int device, TakeScene **out) {
+    *out = nullptr;
+    TakeScene *ts = new (std::nothrow) TakeScene();
+    if (!ts) return fail(TAKE_E_NOMEM, "out of host memory");
+    ts->precision = src->precision, ts->device = device, ts->num_cus = src->num_cus, ts->instrumentation = 0;
+    DeviceGuard guard(device);
+    int rc = guard.ok ? TAKE_OK : fail(TAKE_E_DEVICE, "cannot make the replica's device current");
+    if (!rc) rc = src->precision == TAKE_PRECISION_F64 ? replicate_t(src->d, src->device, ts->d, device)
+                                                       : replicate_t(src->f, src->device, ts->f, device);
+    if (rc) {
+        ts->f.release(), ts->d.release();
+        delete ts;
+        return rc;
+    }
+    *out = ts;
+    return TAKE_OK;
+}
+}  // namespace
+
 struct TakeSceneGroup {
     std::vector<TakeScene *> scenes;  // one per shard, each on its device
     std::vector<void *> staging;      // on the first device: shard k's compact rows (k > 0), copied peer to peer
@@ -1232,7 +1297,8 @@ int take_hip_group_create(const TakeSceneDesc *desc, const TakeBuildOpts *opts, 
             break;
         }
         TakeScene *ts = nullptr;
-        rc = take_hip_scene_create(desc, opts, &ts);  // (the build is deterministic: every replica holds the same tree)
+        // the first shard prepares and builds the scene; the others are peer-to-peer copies of its device arrays
+        rc = k == 0 ? take_hip_scene_create(desc, opts, &ts) : replicate_scene(g->scenes[0], dev, &ts);
         if (!rc) g->scenes.push_back(ts);
     }
     if (!rc) {
