@@ -129,7 +129,7 @@ template <class R> struct SceneT {
     DevBuf<unsigned long long> spill;
     int64_t capacity = 0;  // path slots allocated
     int trace_grid = 0;
-    int group = 4;             // lanes per ray of the trace kernel
+    int group = 2;             // lanes per ray of the trace kernel (the pair kernel is the only instance)
     bool built_on_device = false;
     int64_t spill_stride = 0;  // ray groups in the persistent trace grid
 
@@ -284,11 +284,6 @@ int build_bvh_device(SceneT<float> &sc, int max_leaf, bool compressed_ok, bool c
     HIP_TRY(hipGetLastError());
     return TAKE_OK;
 }
-template <class R> int build_bvh_device_any(SceneT<R> &sc, int max_leaf, bool compressed_ok, bool compressed_forced) {
-    if constexpr (sizeof(R) == 4) return build_bvh_device(sc, max_leaf, compressed_ok, compressed_forced);
-    return 1;
-}
-
 // Primitive records on the device from the caller's arrays (tk_build_gpu.h::k_make_prims): the mesh positions go up as
 // they are (double, one copy per mesh, no host staging), the face indices are the validated concatenation the shading
 // side keeps anyway (sc.face_idx, uploaded here), the four shape arrays go up as they are.

@@ -1,13 +1,14 @@
 // tk_scene.h — device-side scene layout (what lives in HBM) and the path-state SoA.
 //
-// Layout rules (DESIGN.md §HBM layout):
-//  * BVH: 4-wide nodes, one 128-byte record per node in f32 (one L2 line) = four 32-byte child slots
-//    {bmin, bmax, child word}: a traversal quad (4 lanes = 1 ray) reads a node as one coalesced line, one slot
-//    per lane.  Nodes are in breadth-first order, so the top levels are a prefix of the array.
-//  * Primitives are stored in leaf order as pre-transformed records (v0, e1, e2 | centre, radius) so a
-//    leaf is one contiguous run; 48 B in f32.
-//  * Everything the shading stage needs (vertex normals, uvs, materials, lights, texels) is indexed by the
-//    shape id a hit returns; it is touched once per bounce, not per node.
+// Layout rules:
+//  * BVH: 4-wide nodes in breadth-first order (top levels = array prefix).  The render paths of both precisions read
+//    the 64-byte compressed form (QNode4: four 16-byte slots, planes on a 16-bit grid) — a traversal pair loads its
+//    two slots with 2 x dwordx4 per lane, one 64-byte fabric request per node; the full-width form (Node4<R>) is the
+//    builder's output and the fall-back for scenes the grid is too coarse for.
+//  * Primitives are stored in leaf order as pre-transformed 64-byte records (v0, e1, e2 | centre, radius, then the
+//    shading side of the primitive) so a leaf is one contiguous run and a hit costs the shade kernel one line.
+//  * Everything else the shading stage needs (vertex normals, uvs, materials, lights, texels) is touched once per
+//    bounce, not per node.
 //  * Path state is one 128-byte record per path (f32): queues are compacted every bounce, so live slots are
 //    scattered and a lane should consume whole cache lines (see PathState below).
 #pragma once

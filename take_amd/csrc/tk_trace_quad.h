@@ -85,10 +85,12 @@ __device__ __noinline__ tq_entry tq_spill_load(const tq_entry *p) { return *p; }
 //   load(i, ray, tag): ray i of the work list;  store_hit(tag, prim, t, u, v) / store_occlusion(tag, occ):
 //   called by ONE lane of the group.
 template <class R> struct PathIo {  // the render loop: rays in the path state, indexed through a queue
+    static constexpr bool UNIFORM_TMIN = true;  // every ray starts at the same tmin (the ray epsilon): a scalar, not per-lane state
     const PrimRec<R> *prims;
     PathState<R> st;
     const int32_t *queue;
     R eps;
+    __device__ __forceinline__ R tmin() const { return eps; }
     template <bool SHADOW> __device__ __forceinline__ void load(int32_t i, RayT<R> &ray, int32_t &tag) const {
         const int64_t slot = queue[i];
         tag = (int32_t)slot;
@@ -133,6 +135,8 @@ template <> struct HitAoS<double> {
     double t, u, v;
 };
 template <class R> struct HookIo {  // the C-ABI trace hooks: AoS rays in, hit records out
+    static constexpr bool UNIFORM_TMIN = false;
+    __device__ __forceinline__ R tmin() const { return R(0); }
     const PrimRec<R> *prims;
     const RayAoS<R> *rays;
     HitAoS<R> *hits;
@@ -220,7 +224,11 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
     // QN in f64: the box tests run in f32 on the compressed nodes (conservative, so precision is not at stake; hits are
     // decided by the double-precision primitive tests) — the limits enter them rounded outwards
     float tmin_f = 0.0f, tbest_f = 0.0f;
-    auto lim_lo = [&]() -> float { if constexpr (sizeof(R) == 4) return (float)ray.tmin; else return tmin_f; };
+    auto lim_lo = [&]() -> float {
+        if constexpr (Io::UNIFORM_TMIN) return stack_key(io.tmin());  // uniform: stays in a scalar register
+        else if constexpr (sizeof(R) == 4) return (float)ray.tmin;
+        else return tmin_f;
+    };
     auto lim_hi = [&]() -> float { if constexpr (sizeof(R) == 4) return (float)tbest; else return tbest_f; };
     int32_t tag = 0;            // path slot (render) / ray index (trace hooks) of the ray in this slot
     int sp = 0;                 // entries on this group's stack
@@ -300,7 +308,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
             }
             if (!any) {
                 if (gl == 0) {
-                    io.store_hit(tag, -1, ray.tmax, R(0), R(0));
+                    io.store_hit(tag, -1, tbest, R(0), R(0));  // (no hit: tbest is still the ray's tmax — which need not stay live)
                     if (INST) io.store_instance(tag, -1);
                 }
             } else if (mine) {
@@ -524,6 +532,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
             } else if (at_leaf) {
                 const int first = leaf_first(leaf), cnt = leaf_count(leaf);
                 if (COUNT && gl == 0) cnt_prims += (uint32_t)cnt, cnt_leaves++;
+                if constexpr (Io::UNIFORM_TMIN) ray.tmin = io.tmin();  // (re-materialised from the scalar: not kept per lane)
 #pragma unroll 1
                 for (int k = gl; k < cnt; k += G) {
                     const uint32_t off = (uint32_t)(first + k) * (uint32_t)sizeof(PrimRec<R>);

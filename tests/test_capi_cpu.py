@@ -46,7 +46,7 @@ def test_struct_layout_matches_header():
         "TakeMesh": D.TakeMesh, "TakeSphere": D.TakeSphere, "TakeLight": D.TakeLight, "TakeCamera": D.TakeCamera,
         "TakeSceneDesc": D.TakeSceneDesc, "TakeBuildOpts": D.TakeBuildOpts, "TakeRenderOpts": D.TakeRenderOpts,
         "TakeRayF": D.TakeRayF, "TakeRayD": D.TakeRayD, "TakeHitF": D.TakeHitF, "TakeHitD": D.TakeHitD,
-        "TakeCounters": D.TakeCounters,
+        "TakeCounters": D.TakeCounters, "TakeInstance": D.TakeInstance,
     }
     prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "take_hip.h"', "int main(void){"]
     for n, cls in fields.items():
@@ -87,6 +87,22 @@ def test_scene_create_without_gpu_raises(lib):
     with pytest.raises(capi.TakeError) as e:
         capi.Scene(golden_scene("cbox"))
     assert e.value.code == -3
+
+
+def test_group_and_egress_entry_points_without_gpu(lib):
+    """the newer entry points keep the contract: no HIP device -> TAKE_E_NO_GPU, never a fallback"""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from helpers import golden_scene
+
+    with pytest.raises(capi.TakeError) as e:
+        capi.SceneGroup(golden_scene("cbox"), [0, 0])
+    assert e.value.code == -3
+    buf = (C.c_uint16 * 16)()
+    rc = lib.take_hip_pack_exr_scanlines(C.cast(buf, C.c_void_p), 0, 2, 2, C.cast(buf, C.c_void_p), None)
+    assert rc == -3
 
 
 def test_product_never_imports_the_oracle():

@@ -137,7 +137,7 @@ def test_device_build_wide_node_format():
     """TAKE_HIP_NODES=wide with the device builder: full-width nodes straight from the collapse kernel"""
     import os
 
-    if os.environ.get("TAKE_HIP_GROUP") or os.environ.get("TAKE_HIP_NODES"):
+    if os.environ.get("TAKE_HIP_NODES"):
         pytest.skip("experiment knobs select the node format")
 
     sd = scenes.soup_scene(50_000, 128, 128, spp=1)

@@ -45,7 +45,7 @@ def soup1m():
     sc.close()
 
 
-@pytest.mark.skipif(bool(os.environ.get("TAKE_HIP_GROUP") or os.environ.get("TAKE_HIP_NODES")),
+@pytest.mark.skipif(bool(os.environ.get("TAKE_HIP_NODES")),
                     reason="experiment knobs select the node format")
 def test_1m_compressed_nodes_in_use(soup1m):
     soup1m.set_instrumentation(timing=False, counting=True)

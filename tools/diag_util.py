@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from take_amd import capi, scenes
 
-PW = 64 // int(os.environ.get("TAKE_HIP_GROUP", "2"))  # ray slots per wave
+PW = 32  # ray slots per wave (pair kernel)
 tris = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 sd = scenes.soup_scene(tris, 1920, 1080, spp=spp)
