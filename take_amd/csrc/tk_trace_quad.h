@@ -510,7 +510,10 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
         {
             const int32_t leaf = cur;
             const bool at_leaf = (uint32_t)leaf > (uint32_t)CHILD_EMPTY;
-            if (COUNT && lane == 0 && tq_ballot(at_leaf) != 0) cnt_wleaf++;
+            if (COUNT) {  // (the vote must be taken by all lanes: inside `lane == 0 &&` it would see lane 0 alone)
+                const uint64_t m_at_leaf = tq_ballot(at_leaf);
+                if (lane == 0 && m_at_leaf != 0) cnt_wleaf++;
+            }
             if (INST && at_leaf && is_instance_word(leaf)) {
                 // enter the instance (uniform over the lanes of the group: `cur` is)
                 const InstTrace<R> &it = sc.inst_trace[instance_of_word(leaf)];

@@ -9,8 +9,10 @@ from take_amd import capi, scenes
 PW = 32  # ray slots per wave (pair kernel)
 tris = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-sd = scenes.soup_scene(tris, 1920, 1080, spp=spp)
-sc = capi.Scene(sd)
+precision = 1 if (len(sys.argv) > 3 and sys.argv[3] == "f64") else 0
+sd = scenes.soup_scene(tris, 1920, 1080, spp=spp, envmap=(2048, 1024))
+sc = capi.Scene(sd, precision=precision)
+print("precision", "f64" if precision else "f32", "tris", tris, "spp per batch", spp)
 sc.set_instrumentation(timing=True, counting=True)
 sc.render(spp=spp, max_depth=50, seed=0)
 c = sc.counters()
