@@ -159,6 +159,10 @@ struct TakeScene {
     TakeCounters counters{};
     EventPool events;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> timed;
+    // queue lengths read back WITHOUT stalling the launch loop: a ring of pinned words + events (render_impl)
+    static constexpr int POLL_RING = 64;
+    int32_t *poll_host = nullptr;  // POLL_RING pinned words
+    hipEvent_t poll_ev[POLL_RING] = {};
 };
 
 namespace {
@@ -702,6 +706,11 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     HIP_TRY(hipMemsetAsync(sc.counters.p, 0, sc.counters.bytes(), stream));
     hipEvent_t ev_begin = ts->events.get(), ev_end = ts->events.get();
     HIP_TRY(hipEventRecord(ev_begin, stream));
+    if (!ts->poll_host) {
+        HIP_TRY(hipHostMalloc((void **)&ts->poll_host, sizeof(int32_t) * TakeScene::POLL_RING, hipHostMallocDefault));
+        for (int i = 0; i < TakeScene::POLL_RING; i++) HIP_TRY(hipEventCreateWithFlags(&ts->poll_ev[i], hipEventDisableTiming));
+    }
+    int64_t poll_issued = 0, poll_done = 0;
 
     for (int s0 = 0; s0 < o.spp; s0 += spb) {
         const int nb = std::min(spb, o.spp - s0);
@@ -714,6 +723,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
         tm.end();
         const int rounds = o.max_depth + 2;
         int64_t n_bound = n;  // upper bound of the extend-queue length (queues only shrink)
+        (void)hipGetLastError();
         for (int k = 0; k < rounds; k++) {
             const int cur = k & 1, next = cur ^ 1;
             int32_t *n_cur = q + (cur ? Q_N_EXT1 : Q_N_EXT0), *n_next = q + (next ? Q_N_EXT1 : Q_N_EXT0);
@@ -762,16 +772,36 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
                 tm.end();
                 if (dump >= 0 && dump < slots) dump_slot(st, dump, "after trace_shadow", k, stream);
             }
-            // every 4 rounds look at the queue length: it bounds the shade grids of the following rounds, and
-            // launching stops once every path of the batch has ended
-            if ((k & 3) == 3 && k + 1 < rounds) {
-                int32_t alive = 0;
-                HIP_TRY(hipMemcpyAsync(&alive, n_next, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipStreamSynchronize(stream));
-                if (alive == 0) break;
-                n_bound = alive;
+            // Queue length of the next round, read back asynchronously (pinned word + event, polled — the launch loop
+            // never waits for the GPU): any value that has arrived bounds the grids of all later rounds (queues only
+            // shrink), and a zero ends the launching.  (Round 1 blocked on a stream sync every 4 rounds: with the
+            // ~370 launches of a small render that was a third of its 12 ms.)
+            if (k + 1 < rounds && poll_issued - poll_done < TakeScene::POLL_RING) {
+                const int slot = poll_issued % TakeScene::POLL_RING;
+                HIP_TRY(hipMemcpyAsync(ts->poll_host + slot, n_next, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipEventRecord(ts->poll_ev[slot], stream));
+                poll_issued++;
             }
+            bool finished = false;
+            while (poll_done < poll_issued) {
+                const int slot = poll_done % TakeScene::POLL_RING;
+                hipError_t q = hipEventQuery(ts->poll_ev[slot]);
+                if (q == hipErrorNotReady) {
+                    // stay at most 8 rounds ahead of the GPU: enough queued work that it never idles, close enough
+                    // that a batch whose paths have all ended stops being launched
+                    if (poll_issued - poll_done < 8) break;
+                    q = hipEventSynchronize(ts->poll_ev[slot]);
+                }
+                HIP_TRY(q);
+                const int32_t alive = ts->poll_host[slot];
+                poll_done++;
+                n_bound = std::min<int64_t>(n_bound, alive);
+                if (alive == 0) finished = true;
+            }
+            if (finished) break;
         }
+        // (outstanding read-backs of this batch complete with the stream; the ring indices just move on)
+        poll_done = poll_issued;
         tm.begin(TK_OTHER);
         hipLaunchKernelGGL((k_accumulate<R>), dim3(pix_grid), dim3(BLOCK), 0, stream, st, sc.accum.p, (int32_t)npix, nb);
         tm.end();
@@ -960,6 +990,11 @@ int take_hip_scene_destroy(TakeScene *ts) {
     ts->f.release();
     ts->d.release();
     ts->events.destroy();
+    if (ts->poll_host) {
+        (void)hipHostFree(ts->poll_host);
+        for (auto e : ts->poll_ev)
+            if (e) (void)hipEventDestroy(e);
+    }
     delete ts;
     return TAKE_OK;
 }
