@@ -85,6 +85,51 @@ def test_1m_closest_hit_equals_exhaustive_search(soup1m):
     assert np.array_equal(soup1m.trace_any(rays_to_abi(rays, 0)).astype(bool), hit)
 
 
+def test_1m_f64_through_compressed_nodes_equals_exhaustive_search():
+    """f64 scenes traverse the 64-byte compressed nodes with f32 box tests (conservative: limits rounded outwards) and
+    decide hits with the double-precision primitive tests: at 1M triangles closest hits must still equal the
+    exhaustive search of the reference triangle test in double, bit for bit, and the image must equal the one rendered
+    through the full-width double nodes (TAKE_HIP_NODES=wide)."""
+    sd = scenes.soup_scene(1_000_000, 480, 270, spp=1)
+    sc = capi.Scene(sd, precision=D.TAKE_PRECISION_F64)
+    old = os.environ.get("TAKE_HIP_NODES")
+    os.environ["TAKE_HIP_NODES"] = "wide"
+    try:
+        wide = capi.Scene(sd, precision=D.TAKE_PRECISION_F64)
+    finally:
+        if old is None:
+            os.environ.pop("TAKE_HIP_NODES", None)
+        else:
+            os.environ["TAKE_HIP_NODES"] = old
+    try:
+        sc.set_instrumentation(timing=False, counting=True)
+        img = sc.render(spp=1, max_depth=50, seed=4)
+        assert sc.counters()["node_bytes"] == 64
+        sc.set_instrumentation(False, False)
+        wide.set_instrumentation(timing=False, counting=True)
+        img_w = wide.render(spp=1, max_depth=50, seed=4)
+        assert wide.counters()["node_bytes"] == 256
+        assert np.array_equal(img, img_w)
+        rays = random_rays(256, 37, tmin=1e-7)
+        osc = oracle.OracleScene(sd, precision=1)
+        want = osc.isect_brute(rays)
+        osc.close()
+        hits = sc.trace_closest(rays_to_abi(rays, 1))
+        assert np.array_equal(hits["shape_id"], want[:, 0].astype(np.int32))
+        hit = want[:, 0] >= 0
+        assert hit.sum() > 100
+        for k, col in (("t", 1), ("u", 2), ("v", 3)):
+            assert np.array_equal(hits[k][hit], want[hit, col]), k
+        many = rays_to_abi(random_rays(200_000, 41, tmin=1e-7), 1)
+        ha, hb = sc.trace_closest(many), wide.trace_closest(many)
+        for f in ("shape_id", "t", "u", "v"):
+            assert np.array_equal(ha[f], hb[f]), f
+        assert np.array_equal(sc.trace_any(many), wide.trace_any(many))
+    finally:
+        sc.close()
+        wide.close()
+
+
 def test_1m_deterministic_sharded_and_batch_invariant(soup1m):
     full = soup1m.render(spp=2, max_depth=50, seed=9)
     assert np.array_equal(full, soup1m.render(spp=2, max_depth=50, seed=9))
