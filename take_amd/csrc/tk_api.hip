@@ -723,7 +723,6 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
         tm.end();
         const int rounds = o.max_depth + 2;
         int64_t n_bound = n;  // upper bound of the extend-queue length (queues only shrink)
-        (void)hipGetLastError();
         for (int k = 0; k < rounds; k++) {
             const int cur = k & 1, next = cur ^ 1;
             int32_t *n_cur = q + (cur ? Q_N_EXT1 : Q_N_EXT0), *n_next = q + (next ? Q_N_EXT1 : Q_N_EXT0);
@@ -787,6 +786,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
                 const int slot = poll_done % TakeScene::POLL_RING;
                 hipError_t q = hipEventQuery(ts->poll_ev[slot]);
                 if (q == hipErrorNotReady) {
+                    (void)hipGetLastError();  // "not ready" is an answer, not an error: keep it out of the sticky state
                     // stay at most 8 rounds ahead of the GPU: enough queued work that it never idles, close enough
                     // that a batch whose paths have all ended stops being launched
                     if (poll_issued - poll_done < 8) break;

@@ -293,6 +293,78 @@ int main(int argc, char **argv) {
         }
         std::printf("  GPU-order any-hit (slot mode %d): nodes %.2f leaves %.2f per ray\n", mode, (double)un / nr, (double)ul / nr);
     }
+    if (std::getenv("LAB_WIDE8")) {
+        // what would 8-wide nodes buy?  Collapse the same BVH2 to W-wide nodes (open the largest child until W slots
+        // are used) and count node / leaf visits of ordered closest-hit traversal for the same rays.
+        for (int Wd : {4, 8}) {
+            struct WNode { float bmin[8][3], bmax[8][3]; int32_t child[8]; int n; };
+            std::vector<WNode> wn;
+            std::vector<int32_t> worder;
+            const auto &n2 = builder.nodes();
+            struct Item { int n2; };
+            std::vector<Item> queue{{root}};
+            wn.emplace_back();
+            auto leafw = [&](const Bvh2Node &n) { int32_t f = (int32_t)worder.size(); for (int i = 0; i < n.count; i++) worder.push_back(n.first + i); return make_leaf(f, n.count); };
+            for (size_t head = 0; head < queue.size(); head++) {
+                int kids[8], nk = 0;
+                kids[nk++] = n2[queue[head].n2].left, kids[nk++] = n2[queue[head].n2].right;
+                while (nk < Wd) {
+                    int best = -1; double ba = -1;
+                    for (int i = 0; i < nk; i++) { const Bvh2Node &c = n2[kids[i]]; if (c.count > 0) continue; Bounds b; b.grow(c.bmin, c.bmax); if (b.half_area() > ba) ba = b.half_area(), best = i; }
+                    if (best < 0) break;
+                    const int open = kids[best]; kids[best] = n2[open].left; kids[nk++] = n2[open].right;
+                }
+                WNode w{}; w.n = nk;
+                for (int i = 0; i < nk; i++) {
+                    const Bvh2Node &c = n2[kids[i]];
+                    for (int a = 0; a < 3; a++) w.bmin[i][a] = round_down(c.bmin[a], 0.f), w.bmax[i][a] = round_up(c.bmax[a], 0.f);
+                    if (c.count > 0) w.child[i] = leafw(c);
+                    else { w.child[i] = (int32_t)queue.size(); queue.push_back({kids[i]}); wn.emplace_back(); }
+                }
+                wn[head] = w;
+            }
+            std::vector<PrimRec<float>> wp(worder.size());
+            for (size_t k = 0; k < worder.size(); k++) wp[k] = recs[bp[worder[k]].id];
+            std::mt19937_64 r(99);
+            std::uniform_real_distribution<float> V(-1.f, 1.f);
+            uint64_t un = 0, ul = 0, ub = 0; int nr = 0;
+            for (int i = 0; i < n_rays; i += 4, nr++) {
+                const int k = (int)(r() % (uint64_t)nt);
+                const float *p = &tri[9 * k];
+                float o[3], d[3], l2;
+                for (int a = 0; a < 3; a++) o[a] = (p[a] + p[3 + a] + p[6 + a]) / 3.f;
+                do { for (int a = 0; a < 3; a++) d[a] = V(r); l2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2]; } while (l2 > 1.f || l2 < 1e-4f);
+                const float inv = 1.f / std::sqrt(l2);
+                RayT<float> ray = make_ray(o[0], o[1], o[2], d[0] * inv, d[1] * inv, d[2] * inv, 1e-4f, Const<float>::inf());
+                const float idx = safe_inv(ray.d.x), idy = safe_inv(ray.d.y), idz = safe_inv(ray.d.z);
+                float tbest = ray.tmax;
+                struct E { int32_t c; float k; } stk[256]; int sp = 0; int32_t cur = 0;
+                for (;;) {
+                    if (cur >= 0) {
+                        un++;
+                        const WNode &w = wn[cur];
+                        int32_t hc[8]; float hk[8]; int nh = 0;
+                        for (int j = 0; j < w.n; j++) {
+                            NodeChild<float> c{}; for (int a = 0; a < 3; a++) c.bmin[a] = w.bmin[j][a], c.bmax[a] = w.bmax[j][a]; c.child = w.child[j];
+                            float tn; ub++;
+                            if (box_test(c, ray.o, idx, idy, idz, ray.tmin, tbest, tn)) hc[nh] = c.child, hk[nh] = tn, nh++;
+                        }
+                        for (int a2 = 0; a2 < nh; a2++) for (int b2 = a2 + 1; b2 < nh; b2++) if (hk[b2] < hk[a2]) std::swap(hk[a2], hk[b2]), std::swap(hc[a2], hc[b2]);
+                        for (int j = nh - 1; j >= 1; j--) stk[sp++] = E{hc[j], hk[j]};
+                        if (nh) { cur = hc[0]; continue; }
+                    } else if (cur != CHILD_EMPTY) {
+                        ul++;
+                        const int first = leaf_first(cur), cnt = leaf_count(cur);
+                        for (int q = 0; q < cnt; q++) { float t, u, v; if (tri_test(wp[first + q].a, ray, tbest, t, u, v)) tbest = t; }
+                    }
+                    bool done = false;
+                    for (;;) { if (sp == 0) { done = true; break; } --sp; cur = stk[sp].c; if (stk[sp].k <= tbest) break; }
+                    if (done) break;
+                }
+            }
+            std::printf("  %d-wide: nodes %zu, closest-hit node visits %.2f, slot tests %.1f, leaf visits %.2f per ray\n", Wd, wn.size(), (double)un / nr, (double)ub / nr, (double)ul / nr);
+        }
+    }
     if (std::getenv("LAB_ANYORDER")) {
         for (int mode = 0; mode < 5; mode++) {
             std::mt19937_64 r(99);
