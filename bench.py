@@ -174,7 +174,10 @@ def f64_leg(args, sd, img32, stream):
     scene = capi.Scene(sd, precision=D.TAKE_PRECISION_F64, max_leaf_size=args.max_leaf)
     t_setup = time.time() - t0
     out = torch.empty((args.height, args.width, 3), dtype=torch.float64, device="cuda")
-    scene.render_device(out.data_ptr(), 1, args.max_depth, seed=7, stream=stream)  # warms the kernels up
+    # warm-up: kernels loaded AND the batch workspace of the timed steps allocated (same spp -> same batch size; depth 0
+    # keeps it to two rounds) — a first hipMalloc of > 100 GB of path state costs seconds and is not the workload
+    scene.render_device(out.data_ptr(), args.spp, 0, seed=7, samples_per_batch=args.spb, stream=stream)
+    scene.render_device(out.data_ptr(), 1, args.max_depth, seed=7, samples_per_batch=1, stream=stream)
     scene.set_instrumentation(timing=True, counting=False)
     torch.cuda.synchronize()
     t_start = time.perf_counter()
