@@ -736,7 +736,7 @@ V3<R> eval_bsdf(const Material<R> &m, V3<R> dir_in, const SampleRecord<R> &rec, 
     switch (m.tag) {
         case TAKE_MAT_MIRROR: {  // mirror.inl:16-22 — no cosine
             V3<R> F0 = eval_texture(m.reflectance, v.uv, sc);
-            return F0 + s_sub(R(1), F0) * R(std::pow(1 - dot(n, dir_out), 5));
+            return F0 + s_sub(R(1), F0) * std::pow(R(1 - dot(n, dir_out)), R(5));
         }
         case TAKE_MAT_PLASTIC: {  // plastic.inl:40-50 — specular branch detected by pdf == 1
             if (rec.pdf == R(1)) return {R(1), R(1), R(1)};
@@ -753,15 +753,15 @@ V3<R> eval_bsdf(const Material<R> &m, V3<R> dir_in, const SampleRecord<R> &rec, 
             if (dot(n, dir_out) <= 0) return zero;
             V3<R> h = normalize(dir_out + dir_in);
             V3<R> Ks = eval_texture(m.reflectance, v.uv, sc);
-            V3<R> Fh = Ks + s_sub(R(1), Ks) * R(std::pow(1 - dot(h, dir_out), 5));
-            return (m.p0 + 2) * R(0.25) * K<R>::INVPI / (2 - R(std::pow(2, -m.p0 / 2))) * Fh *
+            V3<R> Fh = Ks + s_sub(R(1), Ks) * std::pow(R(1 - dot(h, dir_out)), R(5));
+            return (m.p0 + 2) * R(0.25) * K<R>::INVPI / (2 - std::pow(R(2), -m.p0 / 2)) * Fh *
                    std::pow(std::fmax(R(0), dot(n, h)), m.p0);
         }
         case TAKE_MAT_BLINN_PHONG_MICROFACET: {  // blinn_phong_microfacet.inl:42-59
             V3<R> h = normalize(dir_out + dir_in);
             if (dot(n, dir_out) <= 0 || dot(dir_out, h) <= 0 || dot(dir_in, h) <= 0) return zero;
             V3<R> Ks = eval_texture(m.reflectance, v.uv, sc);
-            V3<R> Fh = Ks + s_sub(R(1), Ks) * R(std::pow(1 - dot(h, dir_out), 5));
+            V3<R> Fh = Ks + s_sub(R(1), Ks) * std::pow(R(1 - dot(h, dir_out)), R(5));
             R Dh = (m.p0 + 2) * K<R>::INVTWOPI * std::pow(clampR(dot(n, h), R(0), R(1)), m.p0);
             R G = blinn_phong_G_hat(dir_out, n, m.p0) * blinn_phong_G_hat(dir_in, n, m.p0);
             return Fh * Dh * G * R(0.25) / dot(n, dir_in);

@@ -4,8 +4,10 @@
 // parse_scene and the tile loop (src/render.cpp:37-50) plus build_bvh (src/scene.cpp:4-23).
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstring>
 #include <cstdlib>
 #include <string>
 #include <thread>
@@ -80,6 +82,49 @@ template <class R> struct HostScene {
         return d;
     }
 };
+
+// Exactly coincident primitives (identical geometry words: e.g. a duplicated face) tie in t AND in (u, v); the trace
+// kernel then lets the larger primitive index win.  For that to mean the same thing in every tree, each group of
+// coincident records inside [begin, end) gets its shape ids (with the shading side of the record) in ascending order of
+// position — the geometry of the group's records is identical, so no box and no leaf changes.  The device builder needs
+// no such pass: its Morton sort is stable, equal codes keep the shape order.
+template <class R> inline void order_coincident(std::vector<PrimRec<R>> &prims, size_t begin, size_t end) {
+    if (end - begin < 2) return;
+    auto geom_hash = [](const PrimRec<R> &p) {
+        uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)(p.meta & 0xff);
+        const unsigned char *b = reinterpret_cast<const unsigned char *>(p.a);
+        for (size_t i = 0; i < sizeof(p.a); i++) h = (h ^ b[i]) * 0x100000001b3ull;
+        return h;
+    };
+    auto same_geom = [](const PrimRec<R> &x, const PrimRec<R> &y) {
+        return (x.meta & 0xff) == (y.meta & 0xff) && std::memcmp(x.a, y.a, sizeof(x.a)) == 0;
+    };
+    std::vector<std::pair<uint64_t, uint32_t>> keys(end - begin);
+    for (size_t i = begin; i < end; i++) keys[i - begin] = {geom_hash(prims[i]), (uint32_t)i};
+    std::sort(keys.begin(), keys.end());
+    std::vector<PrimRec<R>> group;
+    for (size_t i = 0; i < keys.size();) {
+        size_t j = i + 1;
+        while (j < keys.size() && keys[j].first == keys[i].first) j++;
+        if (j - i > 1) {
+            // positions keys[i..j) ascend (sorted by (hash, index)); split the run into true geometry groups
+            std::vector<char> done(j - i, 0);
+            for (size_t a = i; a < j; a++) {
+                if (done[a - i]) continue;
+                std::vector<uint32_t> pos{keys[a].second};
+                for (size_t b = a + 1; b < j; b++)
+                    if (!done[b - i] && same_geom(prims[keys[a].second], prims[keys[b].second])) pos.push_back(keys[b].second), done[b - i] = 1;
+                if (pos.size() > 1) {
+                    group.clear();
+                    for (uint32_t q : pos) group.push_back(prims[q]);
+                    std::sort(group.begin(), group.end(), [](const PrimRec<R> &x, const PrimRec<R> &y) { return x.shape_id < y.shape_id; });
+                    for (size_t q = 0; q < pos.size(); q++) prims[pos[q]] = group[q];
+                }
+            }
+        }
+        i = j;
+    }
+}
 
 // Camera basis of src/render.cpp:37-44, in R arithmetic.
 template <class R> inline void make_camera(const TakeCamera &c, CameraRec<R> &out) {
@@ -513,6 +558,7 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
                 b.depth = bst.depth;
                 b.prims.resize(border.size());
                 for (size_t k = 0; k < border.size(); k++) b.prims[k] = brecs[bbp[border[k]].id];
+                order_coincident(b.prims, 0, b.prims.size());
                 max_blas_depth = std::max(max_blas_depth, b.depth);
             }
             inst_blas[i] = blas_of_mesh[in.mesh_id];
@@ -644,6 +690,7 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
     }
     return "";
     });
+    if (build_bvh) order_coincident(hs.prims, 0, order.size());  // (device build: the stable Morton sort does it)
     if (3 * hs.stats.depth + 2 > MAX_STACK_ENTRIES) return "BVH too deep for the traversal stack";
     return "";
 }

@@ -20,6 +20,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include "tk_traverse.h"
 
 namespace tk {
@@ -280,9 +282,10 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
             if (gl == 0) io.store_occlusion(tag, occ);
         } else {
             // the lane holding the closest candidate writes it.  At exactly equal distances (a ray through an edge
-            // shared by two triangles) the candidate with the larger (u, v) wins, here and in the leaf phase: a rule
-            // on values every tree produces identically, so the image does not depend on the builder — and one that
-            // needs no load (the end of a ray is on the critical path of the wave).
+            // shared by two triangles) the candidate with the larger (u, v) wins, here and in the leaf phase — then, for
+            // exactly coincident primitives, the larger shape id: a rule on values every tree produces identically,
+            // so the image does not depend on the builder — and one that needs no load on the common path (the end
+            // of a ray is on the critical path of the wave).
             bool mine = my_prim >= 0 && my_t == tbest;
             bool any = mine;
             if (!TQ_TIEBREAK) {
@@ -292,7 +295,19 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                 const bool pm = dpp_i<QP_X1>((int)mine) != 0;
                 const R pu = dpp_f<QP_X1>(my_u), pv = dpp_f<QP_X1>(my_v);
                 any = any || pm;
-                if (mine && pm && (pu > my_u || (pu == my_u && (pv > my_v || (pv == my_v && (gl & 1) == 0))))) mine = false;
+                if (mine && pm) {
+                    // (t, u, v) all equal = exactly coincident primitives: the larger (instance, primitive index) wins.
+                    // Both builders lay coincident primitives out with ascending shape ids (tk_host_scene.h:
+                    // order_coincident; the device build's stable Morton sort), so this is "the larger shape id" —
+                    // a rule every tree applies alike — decided on registers, without a load.
+                    const int32_t pp = dpp_i<QP_X1>(my_prim);
+                    bool lose = pu > my_u || (pu == my_u && (pv > my_v || (pv == my_v && pp > my_prim)));
+                    if (INST) {
+                        const int32_t pi = dpp_i<QP_X1>(my_inst);
+                        if (pu == my_u && pv == my_v && pi != my_inst) lose = pi > my_inst;
+                    }
+                    if (lose) mine = false;
+                }
             }
             if (TQ_TIEBREAK && G >= 4) {  // winners of the two pairs against each other
                 const bool pm = dpp_i<QP_X2>((int)mine) != 0;
@@ -547,7 +562,10 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                     const bool ok = ((p.meta & 0xff) == PRIM_TRIANGLE) ? tri_test(p.a, ray, tlim, t, u, v)
                                                                        : sphere_test(p.a, ray, tlim, t);
                     bool take = ok;
-                    if (TQ_TIEBREAK && ok && t == my_t) take = u > my_u || (u == my_u && v > my_v);  // rare: an exact tie
+                    if (TQ_TIEBREAK && ok && t == my_t) {  // rare: an exact tie; coincident primitives: larger (instance, index)
+                        take = u > my_u || (u == my_u && (v > my_v || (v == my_v && first + k > my_prim)));
+                        if (INST && u == my_u && v == my_v && inst != my_inst) take = inst > my_inst;
+                    }
                     if (take) {
                         my_t = t, my_u = u, my_v = v;
                         my_prim = first + k;

@@ -270,7 +270,8 @@ TK_HD void traverse(const DeviceScene<R> &sc, const RayT<R> &ray, Stack &stack, 
             HitT<R> h2;
             Stack s2;
             traverse<R, ANY_HIT, COUNT>(sub, r2, s2, h2, tc);
-            if (h2.prim >= 0 && (h2.t < tbest || hit.prim < 0 || h2.u > hit.u || (h2.u == hit.u && h2.v > hit.v))) {
+            if (h2.prim >= 0 && (h2.t < tbest || hit.prim < 0 || h2.u > hit.u ||
+                                 (h2.u == hit.u && (h2.v > hit.v || (h2.v == hit.v && (id > hit.inst || (id == hit.inst && h2.prim > hit.prim))))))) {
                 tbest = h2.t;
                 hit = h2;
                 hit.inst = id;
@@ -286,7 +287,9 @@ TK_HD void traverse(const DeviceScene<R> &sc, const RayT<R> &ray, Stack &stack, 
                 R t, u = R(0), v = R(0);
                 bool ok = ((p.meta & 0xff) == PRIM_TRIANGLE) ? tri_test(p.a, ray, tbest, t, u, v)
                                                              : sphere_test(p.a, ray, tbest, t);
-                if (ok && (t < tbest || hit.prim < 0 || u > hit.u || (u == hit.u && v > hit.v))) {  // ties: larger (u, v), any tree
+                // ties in t: larger (u, v), then (coincident primitives) the larger primitive index = the larger shape
+                // id (the builders order coincident primitives that way) — the same in any tree
+                if (ok && (t < tbest || hit.prim < 0 || u > hit.u || (u == hit.u && (v > hit.v || (v == hit.v && first + k > hit.prim))))) {
                     tbest = t;
                     hit.shape = p.shape_id;
                     hit.prim = first + k;

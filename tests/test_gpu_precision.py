@@ -129,3 +129,50 @@ def test_exact_ties_vs_reference_visiting_order(precision):
     gu, gv = got["u"][differ].astype(np.float64), got["v"][differ].astype(np.float64)
     ru, rv = ref[differ, 17], ref[differ, 18]
     assert np.all((gu > ru) | ((gu == ru) & (gv >= rv)))  # the documented rule: larger (u, v) wins
+
+
+def _coincident_scene():
+    """three exactly coincident triangles (same vertices) with DIFFERENT vertex normals and materials, among a few
+    others: (t, u, v) of a ray are identical for all three"""
+    sd = SceneData(width=48, height=48, lookfrom=(0.0, 0.3, 3.0), lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), vfov=40.0,
+                   background=(0.2, 0.2, 0.3), spp=4, max_depth=3)
+    mats = [sd.add_material(D.MAT_DIFFUSE, c) for c in ((0.8, 0.1, 0.1), (0.1, 0.8, 0.1), (0.1, 0.1, 0.8), (0.6, 0.6, 0.6))]
+    tri = np.array([[-0.8, -0.5, 0.0], [0.8, -0.5, 0.1], [0.0, 0.9, -0.1]])
+    rng = np.random.default_rng(2)
+    for k in range(3):
+        n = np.array([[0.1 * k, 0.2, 1.0]] * 3) + rng.normal(0, 0.05, (3, 3))
+        sd.add_mesh(tri, [[0, 1, 2]], mats[k], normals=n / np.linalg.norm(n, axis=1, keepdims=True), uvs=rng.uniform(0, 1, (3, 2)))
+    pos, idx = scenes.soup_triangles(200, 5, 0.9, 0.1)
+    sd.add_mesh(pos + np.array([0, 0, -0.6]), idx, mats[3])
+    lp, li, ln, lu = scenes._quad((0, 1.6, 0.5), (0.5, 0, 0), (0, 0, 0.5), (0, -1, 0))
+    sd.add_mesh(lp, li, mats[3], normals=ln, uvs=lu, emission=(9.0, 9.0, 9.0))
+    return sd
+
+
+@pytest.mark.parametrize("precision", [D.TAKE_PRECISION_F32, D.TAKE_PRECISION_F64])
+def test_coincident_primitives_resolve_by_shape_id_in_every_tree(precision):
+    """Exactly coincident primitives tie in t AND (u, v): the larger shape id wins (found by the fuzz tests: before,
+    the winner depended on the visiting order, i.e. on the tree).  Host and device builders, compressed and
+    full-width nodes: one image; the trace hook reports the largest of the coincident shape ids."""
+    import os
+
+    sd = _coincident_scene()
+    rays = np.array([[0.0, 0.1, 3.0, 0.0, 0.0, -1.0, 1e-4, np.inf], [0.2, -0.1, 2.0, 0.01, 0.02, -1.0, 1e-4, np.inf]])
+    rays[:, 3:6] /= np.linalg.norm(rays[:, 3:6], axis=1, keepdims=True)
+    if precision == D.TAKE_PRECISION_F32:
+        rays = rays.astype(np.float32).astype(np.float64)
+    imgs = []
+    for builder, fmt in ((D.TAKE_BUILDER_HOST_SAH, None), (D.TAKE_BUILDER_DEVICE_LBVH, None), (D.TAKE_BUILDER_HOST_SAH, "wide")):
+        if fmt:
+            os.environ["TAKE_HIP_NODES"] = fmt
+        try:
+            sc = capi.Scene(sd, precision=precision, builder=builder, max_leaf_size=1 if builder == D.TAKE_BUILDER_HOST_SAH and fmt else 0)
+        finally:
+            os.environ.pop("TAKE_HIP_NODES", None)
+        try:
+            hits = sc.trace_closest(rays_to_abi(rays, precision))
+            assert list(hits["shape_id"]) == [2, 2]  # shapes 0, 1, 2 coincide: the largest id
+            imgs.append(sc.render(spp=4, max_depth=3, seed=6))
+        finally:
+            sc.close()
+    assert np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[0], imgs[2])
