@@ -77,3 +77,30 @@ def random_rays(sd, scale, n, seed, tmin):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     tmax = np.where(rng.uniform(size=(n, 1)) < 0.3, rng.uniform(0.05, 3, (n, 1)) * scale, np.inf)
     return np.hstack([o, d, np.full((n, 1), tmin * scale), tmax])
+
+
+def add_random_instances(sd, scale, seed):
+    """1-3 prototype meshes (some with vertex normals and uvs, one zero-area face) under 2-6 placements each: affine
+    transforms with scale, shear and — a third of them — a mirror (negative determinant); random material override"""
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(int(rng.integers(1, 4))):
+        n = int(rng.integers(2, 30))
+        v = rng.uniform(-0.25, 0.25, (n, 3, 3))
+        if n > 3:
+            v[0, 2] = v[0, 1]
+        nrm = uv = None
+        if rng.uniform() < 0.5:
+            nrm = rng.normal(size=(3 * n, 3))
+            nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+            uv = rng.uniform(0, 1, (3 * n, 2))
+        proto = sd.add_prototype(v.reshape(-1, 3) * scale, np.arange(3 * n, dtype=np.int32).reshape(n, 3),
+                                 int(rng.integers(0, 12)), normals=nrm, uvs=uv)
+        for _ in range(int(rng.integers(2, 7))):
+            L = np.eye(3) + rng.uniform(-0.6, 0.6, (3, 3))
+            if rng.uniform() < 0.3:
+                L[:, 0] *= -1
+            if abs(np.linalg.det(L)) < 0.05:
+                L = np.eye(3)
+            t = rng.uniform(-0.7, 0.7, 3) * scale
+            sd.add_instance(proto, np.concatenate([L, t[:, None]], axis=1), int(rng.integers(-1, 12)))
+    return sd

@@ -67,7 +67,62 @@ def test_host_shear_normals_and_material_override():
     assert rmse(ia, ib) < 1e-12 and ia.mean() > 0.05
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 5, 8, 13])
+def test_host_random_scenes_with_sheared_and_mirrored_placements(seed):
+    from fuzz_scenes import add_random_instances, random_rays, random_scene
+
+    sd, scale = random_scene(seed, res=16)
+    add_random_instances(sd, scale, seed)
+    fl = sd.flattened()
+    for precision in (1, 0):
+        rays = random_rays(sd, scale, 800, seed, 1e-7 if precision else 1e-4)
+        if precision == 0:
+            rays = rays.astype(np.float32).astype(np.float64)
+        a = hostsim_trace(sd, precision, rays).astype(np.float64)
+        b = hostsim_trace(fl, precision, rays).astype(np.float64)
+        same = a[:, 0] == b[:, 0]
+        assert same.mean() > 0.995
+        hit = same & (a[:, 0] >= 0)
+        assert (np.abs(a[hit, 1] - b[hit, 1]) / np.maximum(scale, b[hit, 1])).max() < (1e-12 if precision else 1e-4)
+        ia, _ = hostsim_render(sd, precision, 2, 4, seed=seed)
+        ib, _ = hostsim_render(fl, precision, 2, 4, seed=seed)
+        d = np.abs(ia.astype(np.float64) - ib).max(axis=2)
+        assert (d > (1e-9 if precision else 1e-3)).mean() < 0.02  # a path may flip at an edge; nothing systematic
+
+
 # ------------------------------------------------------------------ GPU, through the C ABI
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 5, 8, 13])
+def test_gpu_random_scenes_with_sheared_and_mirrored_placements(seed):
+    from fuzz_scenes import add_random_instances, random_rays, random_scene
+    from take_amd import capi
+
+    sd, scale = random_scene(seed, res=24)
+    add_random_instances(sd, scale, seed)
+    fl = sd.flattened()
+    for precision in (D.TAKE_PRECISION_F64, D.TAKE_PRECISION_F32):
+        f64 = precision == D.TAKE_PRECISION_F64
+        a, b = capi.Scene(sd, precision=precision), capi.Scene(fl, precision=precision)
+        try:
+            rays = random_rays(sd, scale, 20000, seed, 1e-7 if f64 else 1e-4)
+            if not f64:
+                rays = rays.astype(np.float32).astype(np.float64)
+            ha, hb = a.trace_closest(rays_to_abi(rays, precision)), b.trace_closest(rays_to_abi(rays, precision))
+            same = ha["shape_id"] == hb["shape_id"]
+            assert same.mean() > 0.995, same.mean()
+            hit = same & (ha["shape_id"] >= 0)
+            dt = np.abs(ha["t"][hit].astype(np.float64) - hb["t"][hit]) / np.maximum(scale, hb["t"][hit])
+            assert dt.max() < (1e-12 if f64 else 1e-4), dt.max()
+            assert np.array_equal(a.trace_any(rays_to_abi(rays, precision)).astype(bool), ha["shape_id"] >= 0)
+            ia, ib = a.render(spp=4, max_depth=4, seed=seed), b.render(spp=4, max_depth=4, seed=seed)
+            d = np.abs(ia.astype(np.float64) - ib).max(axis=2)
+            assert (d > (1e-8 if f64 else 1e-3) * max(1.0, float(ib.max()))).mean() < 0.03
+        finally:
+            a.close()
+            b.close()
+
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", [D.TAKE_PRECISION_F64, D.TAKE_PRECISION_F32])
 def test_gpu_instanced_equals_flattened(precision):
