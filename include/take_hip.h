@@ -53,7 +53,17 @@ enum TakeMaterialTag {
     TAKE_MAT_DISNEY_CLEARCOAT = 9,
     TAKE_MAT_DISNEY_SHEEN = 10,
     TAKE_MAT_DISNEY_BSDF = 11,
-    TAKE_MAT_COUNT = 12
+    /* EXTENSION (not reference behaviour): the lobes the reference's README promises where its
+     * src/materials/disney_{metal,glass,clearcoat,sheen,bsdf}.inl hold Lambert clones — Burley's
+     * model in the five-lobe form of UCSD CSE 272 homework 1; specification: DESIGN.md §4d and
+     * oracle/take_burley.hpp.  Tag = the reference alternative's tag + 5; a scene made from reference
+     * materials gets them through TakeBuildOpts.burley_lobes. */
+    TAKE_MAT_BURLEY_METAL = 12,
+    TAKE_MAT_BURLEY_GLASS = 13,
+    TAKE_MAT_BURLEY_CLEARCOAT = 14,
+    TAKE_MAT_BURLEY_SHEEN = 15,
+    TAKE_MAT_BURLEY_BSDF = 16,
+    TAKE_MAT_COUNT = 17
 };
 
 /* reference `Texture = variant<ConstTexture, ImageTexture>` (src/texture.h:16-27) */
@@ -64,17 +74,26 @@ typedef struct TakeTexture {
     double uscale, vscale, uoffset, voffset;
 } TakeTexture;
 
-/* One alternative of reference `Material`.  `param[]` meaning by tag:
- *   MIRROR, PLASTIC:            param[0] = eta
- *   PHONG, BLINN_PHONG, _MICROFACET: param[0] = exponent
- *   DISNEY_DIFFUSE:             param[0] = roughness, param[1] = subsurface
- *   others:                     unused on the path (src/materials/disney_*.inl are
- *                               Lambert clones; CLEARCOAT evaluates to zero).     */
+/* One alternative of reference `Material`.  `param[]` = the alternative's scalar members in
+ * declaration order (src/material.h:7-80), after `reflectance`:
+ *   MIRROR, PLASTIC:                 eta
+ *   PHONG, BLINN_PHONG, _MICROFACET: exponent
+ *   DISNEY_DIFFUSE:                  roughness, subsurface
+ *   DISNEY_METAL / BURLEY_METAL:     roughness, anisotropic
+ *   DISNEY_GLASS / BURLEY_GLASS:     roughness, anisotropic, eta
+ *   DISNEY_CLEARCOAT / BURLEY_CLEARCOAT: clearcoat_gloss
+ *   DISNEY_SHEEN / BURLEY_SHEEN:     sheen_tint
+ *   DISNEY_BSDF / BURLEY_BSDF:       specular_transmission, metallic, subsurface, specular, roughness,
+ *                                    specular_tint, anisotropic, sheen, sheen_tint, clearcoat,
+ *                                    clearcoat_gloss, eta
+ * Tags 7..11 ignore their parameters, as the reference does (Lambert clones; CLEARCOAT evaluates
+ * to zero); tags 12..16 use them.                                                              */
+#define TAKE_MATERIAL_PARAMS 12
 typedef struct TakeMaterial {
     int32_t tag;
     int32_t reserved;
     TakeTexture reflectance;
-    double param[4];
+    double param[TAKE_MATERIAL_PARAMS];
 } TakeMaterial;
 
 /* reference `Image3` (src/image.h:13-39): texel (x,y) at data[(y*width+x)*3 + c] */
@@ -176,6 +195,9 @@ typedef struct TakeBuildOpts {
                               made on the GPU straight from the caller's mesh arrays (10M triangles: 0.2 s);
                               TAKE_BUILDER_HOST_SAH: binned SAH on the host (10M triangles: 6 s; traversal 2-6 %
                               faster).  Results do not depend on the builder (conservative box tests).          */
+    int32_t burley_lobes;  /* 0: materials as given (tags 7..11 behave as the reference's stubs do);
+                              1: tags 7..11 are taken as 12..16 — the scene's Disney materials get real lobes */
+    int32_t reserved;
 } TakeBuildOpts;
 #define TAKE_BUILDER_AUTO 0
 #define TAKE_BUILDER_DEVICE_LBVH 1

@@ -28,7 +28,7 @@ def lib():
         L = C.CDLL(so)
         dp = C.POINTER(C.c_double)
         for name in ("random_real", "slab", "tri", "sphere", "to_world", "hemicos", "material", "texture", "light",
-                     "bvh"):
+                     "bvh", "burley"):
             fn = getattr(L, "oracle_tab_" + name)
             fn.argtypes = [dp, C.c_int64, dp]
             fn.restype = None
@@ -54,7 +54,8 @@ def _dp(a):
 
 
 TABLE_COLS = {"random_real": (1, 64), "slab": (14, 1), "tri": (34, 15), "sphere": (12, 15), "to_world": (6, 3),
-              "hemicos": (1, 4), "material": (27, 14), "texture": (6, 3), "light": (30, 9)}
+              "hemicos": (1, 4), "material": (27, 14), "texture": (6, 3), "light": (30, 9),
+              "burley": (30, 14)}
 
 
 def table(name, inp):

@@ -169,6 +169,59 @@ def scene_meshlight(w=64, h=64, spp=8):
             + "</scene>\n")
 
 
+def scene_disney(w=64, h=64, spp=8):
+    # every Disney alternative of the reference's Material with explicit parameters (src/parse/parse_scene.cpp:562-700):
+    # upstream renders Lambert clones of them (src/materials/disney_*.inl) — that is what the render golden of this
+    # scene pins; the flattened parameters feed the Burley lobes (tags 12..16, TakeBuildOpts.burley_lobes)
+    return (HEAD.format(spp=spp, w=w, h=h)
+            + '  <background><rgb name="radiance" value="0 0 0"/></background>\n'
+            + '  <bsdf type="disneymetal" id="metal"><rgb name="baseColor" value="0.95 0.64 0.54"/><float name="roughness" value="0.35"/><float name="anisotropic" value="0.7"/></bsdf>\n'
+            + '  <bsdf type="disneyglass" id="glass"><rgb name="baseColor" value="0.95 0.97 1.0"/><float name="roughness" value="0.15"/><float name="eta" value="1.5"/></bsdf>\n'
+            + '  <bsdf type="disneyglass" id="glass2"><rgb name="baseColor" value="1.0 0.85 0.7"/><float name="roughness" value="0.3"/><float name="anisotropic" value="0.4"/><float name="eta" value="1.33"/></bsdf>\n'
+            + '  <bsdf type="disneyclearcoat" id="coat"><float name="clearcoatGloss" value="0.6"/></bsdf>\n'
+            + '  <bsdf type="disneysheen" id="sheen"><rgb name="baseColor" value="0.3 0.5 0.9"/><float name="sheenTint" value="0.7"/></bsdf>\n'
+            + '  <bsdf type="disneybsdf" id="pr1"><rgb name="baseColor" value="0.8 0.3 0.2"/><float name="specularTransmission" value="0.6"/>'
+            + '<float name="roughness" value="0.25"/><float name="clearcoat" value="0.8"/><float name="clearcoatGloss" value="0.5"/>'
+            + '<float name="sheen" value="0.4"/><float name="eta" value="1.45"/></bsdf>\n'
+            + '  <bsdf type="principled" id="pr2"><rgb name="baseColor" value="0.9 0.75 0.3"/><float name="metallic" value="0.8"/>'
+            + '<float name="roughness" value="0.4"/><float name="anisotropic" value="0.6"/><float name="specularTint" value="0.5"/>'
+            + '<float name="subsurface" value="0.3"/></bsdf>\n'
+            + WALLS.format(back="white", floor="white") + QUADLIGHT
+            + '  <shape type="sphere"><point name="center" x="-0.6" y="-0.69" z="-0.3"/><float name="radius" value="0.3"/><ref id="metal"/></shape>\n'
+            + '  <shape type="sphere"><point name="center" x="0.1" y="-0.67" z="0.35"/><float name="radius" value="0.32"/><ref id="glass"/></shape>\n'
+            + '  <shape type="sphere"><point name="center" x="0.65" y="-0.74" z="-0.35"/><float name="radius" value="0.25"/><ref id="sheen"/></shape>\n'
+            + '  <shape type="sphere"><point name="center" x="-0.55" y="0.0" z="-0.55"/><float name="radius" value="0.27"/><ref id="pr1"/></shape>\n'
+            + '  <shape type="sphere"><point name="center" x="0.55" y="0.05" z="-0.5"/><float name="radius" value="0.27"/><ref id="pr2"/></shape>\n'
+            # no shape refers to "coat": upstream's DisneyClearcoat eval returns an uninitialised vector
+            # (disney_clearcoat.inl:26), so a render with it cannot be a golden; the material is declared for the
+            # flattened parameter
+            + '  <shape type="ply"><string name="filename" value="cube.ply"/><boolean name="faceNormals" value="true"/><ref id="glass2"/></shape>\n'
+            + "</scene>\n")
+
+
+def make_disney():
+    """`python oracle/gen_golden.py disney`: scenes/disney.xml (+ cube.ply), its flattened .tkscene and the reference's
+    own render of it, added to the manifest without touching the other fixtures."""
+    with open(os.path.join(GOLD, "manifest.json")) as f:
+        man = json.load(f)
+    c = np.array([-0.15, -0.79, -0.5])
+    v = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], np.float64) * 0.2 + c
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    faces = [t for a, b, cc, d in quads for t in ((a, b, cc), (a, cc, d))]
+    write_ply(os.path.join(SCENES, "cube.ply"), v, np.array(faces, np.int32))
+    xml = os.path.join(SCENES, "disney.xml")
+    with open(xml, "w") as f:
+        f.write(scene_disney())
+    run("flatten", xml, os.path.join(SCENES, "disney.tkscene"))
+    os.makedirs(RENDER, exist_ok=True)
+    out = os.path.join(RENDER, "disney_d8.f64")
+    run("render", xml, 8, 4, out)
+    a = np.fromfile(out, "<f8")
+    man["render/disney_d8"] = {"w": int(a[0]), "h": int(a[1]), "mean": float(a[2:].mean())}
+    with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+        json.dump(man, f, indent=1, sort_keys=True)
+
+
 def make_scene_files():
     os.makedirs(SCENES, exist_ok=True)
     # 8x4 texture
@@ -393,6 +446,9 @@ def main():
         return
     if sys.argv[1:] == ["integrators"]:
         make_integrator_tables()
+        return
+    if sys.argv[1:] == ["disney"]:
+        make_disney()
         return
     man = {}
     names = make_scene_files()

@@ -145,6 +145,42 @@ void oracle_tab_material(const double *in, int64_t n, double *out) {
         o[13] = rec ? get_bsdf_pdf(m, dir_in, rec->dir_out, v, sc) : 0.0;
     }
 }
+// Burley lobes (tags 12..16; no upstream table: parity unpinned).  Row: tag, colour[3], param[12], geo_normal[3],
+// shading_normal[3], dir_in[3], dir_out[3], mt19937 seed, back_face -> the 14 output columns of the material table.
+void oracle_tab_burley(const double *in, int64_t n, double *out) {
+    Scene<double> sc;
+    for (int64_t r = 0; r < n; r++) {
+        const double *p = in + 30 * r;
+        double *o = out + 14 * r;
+        Material<double> m{};
+        m.tag = (int)p[0];
+        m.reflectance = {0, 0, P3(p + 1), 1, 1, 0, 0};
+        for (int k = 0; k < 12; k++) m.q[k] = p[4 + k];
+        m.p0 = m.q[0], m.p1 = m.q[1];
+        Intersection<double> v{};
+        v.geo_normal = P3(p + 16);
+        v.shading_normal = P3(p + 19);
+        v.t = 1;
+        v.area_light_id = -1;
+        v.back_face = p[29] != 0;
+        V3<double> dir_in = P3(p + 22), dir_out = P3(p + 25);
+        MtRng rng((unsigned)p[28]);
+        auto rec = sample_bsdf(m, dir_in, v, sc, rng);
+        double next = rng.real();
+        for (int i = 0; i < 14; i++) o[i] = 0.0;
+        if (rec) {
+            o[0] = 1.0;
+            put3(o + 1, rec->dir_out);
+            o[4] = rec->pdf;
+            put3(o + 6, eval_bsdf(m, dir_in, *rec, v, sc));
+            o[13] = get_bsdf_pdf(m, dir_in, rec->dir_out, v, sc);
+        }
+        o[5] = next;
+        o[9] = get_bsdf_pdf(m, dir_in, dir_out, v, sc);
+        SampleRecord<double> given{dir_out, 0.0};
+        put3(o + 10, eval_bsdf(m, dir_in, given, v, sc));
+    }
+}
 void oracle_tab_texture(const double *in, int64_t n, double *out) {
     Scene<double> sc;
     sc.images.push_back(table_image());

@@ -166,6 +166,7 @@ template <class R> struct Intersection {  // intersection.h:4-12 (+ shape_id, fo
     int material_id, area_light_id;
     int shape_id;
     R bu, bv;  // Möller–Trumbore barycentrics (not in the reference struct)
+    bool back_face;  // geo_normal was flipped to face the ray (not in the reference struct; take_burley.hpp)
 };
 template <class R> struct PointAndNormal {
     V3<R> position, normal;
@@ -209,6 +210,7 @@ template <class R> struct Material {  // material.h:7-93
     int tag;
     Texture<R> reflectance;
     R p0, p1;
+    R q[12];  // every TakeMaterial::param (tags 12..16, oracle/take_burley.hpp); p0 = q[0], p1 = q[1]
 };
 template <class R> struct Image3 {  // image.h:13-39
     int width, height;
@@ -294,7 +296,9 @@ template <class R> void scene_from_desc(const TakeSceneDesc &d, Scene<R> &s) {
         s.materials[i] = {m.tag,
                           {t.kind, t.image_id, cv3<R>(t.value), R(t.uscale), R(t.vscale), R(t.uoffset), R(t.voffset)},
                           R(m.param[0]),
-                          R(m.param[1])};
+                          R(m.param[1]),
+                          {}};
+        for (int k = 0; k < TAKE_MATERIAL_PARAMS; k++) s.materials[i].q[k] = R(m.param[k]);
     }
     s.images.resize(d.n_images);
     for (int i = 0; i < d.n_images; i++) {
@@ -465,6 +469,7 @@ std::optional<Intersection<R>> intersect_sphere(const Shape<R> &s, int shape_id,
     v.t = root;
     v.pos = r.origin + r.dir * v.t;
     v.geo_normal = normalize(v.pos - s.center);
+    v.back_face = !(dot(r.dir, v.geo_normal) < 0);
     v.geo_normal = dot(r.dir, v.geo_normal) < 0 ? v.geo_normal : -v.geo_normal;
     v.shading_normal = v.geo_normal;
     v.material_id = s.material_id;
@@ -497,6 +502,7 @@ std::optional<Intersection<R>> intersect_triangle(const std::vector<Mesh<R>> &me
     in.t = t;
     in.pos = r.origin + r.dir * t;
     in.geo_normal = normalize(cross(e1, e2));
+    in.back_face = !(dot(r.dir, in.geo_normal) < 0);
     in.geo_normal = dot(r.dir, in.geo_normal) < 0 ? in.geo_normal : -in.geo_normal;
     in.material_id = mesh.material_id;
     in.area_light_id = tri.area_light_id;
@@ -642,9 +648,14 @@ template <class R, class Rng> inline V3<R> sample_power_lobe(R exponent, Rng &rn
     return normalize(V3<R>{std::cos(phi) * sqrt_u1, std::sin(phi) * sqrt_u1, clampR(std::pow(u1, ra1), R(0), R(1))});
 }
 
+}  // namespace oracle
+#include "take_burley.hpp"  // tags 12..16 (extension; parity unpinned, see its header)
+namespace oracle {
+
 template <class R, class Rng>
 std::optional<SampleRecord<R>> sample_bsdf(const Material<R> &m, V3<R> dir_in, const Intersection<R> &v,
                                            const Scene<R> &sc, Rng &rng) {
+    if (is_burley<R>(m.tag)) return burley_sample(m, dir_in, v, rng);
     if (dot(v.geo_normal, dir_in) < 0) return {};  // first statement of every sample_bsdf_op
     V3<R> n = facing_normal(dir_in, v);
     SampleRecord<R> rec;
@@ -699,6 +710,7 @@ std::optional<SampleRecord<R>> sample_bsdf(const Material<R> &m, V3<R> dir_in, c
 
 template <class R>
 R get_bsdf_pdf(const Material<R> &m, V3<R> dir_in, V3<R> dir_out, const Intersection<R> &v, const Scene<R> &) {
+    if (is_burley<R>(m.tag)) return burley_pdf(m, dir_in, dir_out, v);
     if (m.tag == TAKE_MAT_MIRROR) return R(0);  // mirror.inl:12-14
     if (dot(v.geo_normal, dir_out) < 0) return R(0);
     V3<R> n = facing_normal(dir_in, v);
@@ -730,6 +742,7 @@ template <class R>
 V3<R> eval_bsdf(const Material<R> &m, V3<R> dir_in, const SampleRecord<R> &rec, const Intersection<R> &v,
                 const Scene<R> &sc) {
     const V3<R> zero{R(0), R(0), R(0)};
+    if (is_burley<R>(m.tag)) return burley_eval(m, dir_in, rec.dir_out, v, sc);
     if (dot(v.geo_normal, dir_in) < 0 || dot(v.geo_normal, rec.dir_out) < 0) return zero;
     V3<R> n = facing_normal(dir_in, v);
     const V3<R> &dir_out = rec.dir_out;
@@ -766,21 +779,8 @@ V3<R> eval_bsdf(const Material<R> &m, V3<R> dir_in, const SampleRecord<R> &rec, 
             R G = blinn_phong_G_hat(dir_out, n, m.p0) * blinn_phong_G_hat(dir_in, n, m.p0);
             return Fh * Dh * G * R(0.25) / dot(n, dir_in);
         }
-        case TAKE_MAT_DISNEY_DIFFUSE: {  // disney_diffuse.inl:22-46
-            V3<R> h = normalize(dir_in + dir_out);
-            R hdout = dot(h, dir_out), ndout = dot(n, dir_out), ndin = dot(n, dir_in);
-            V3<R> Kd = eval_texture(m.reflectance, v.uv, sc);
-            auto F = [](V3<R> w, V3<R> nn, R FF) { return 1 + (FF - 1) * std::pow(1 - dot(nn, w), R(5)); };
-            R roughness = m.p0, subsurface = m.p1;
-            R F_D90 = R(0.5) + 2 * roughness * hdout * hdout;
-            V3<R> f_base = Kd * K<R>::INVPI * F(dir_in, n, F_D90) * F(dir_out, n, F_D90) * ndout;
-            R F_SS90 = roughness * hdout * hdout;
-            V3<R> f_ss = R(1.25) * Kd * K<R>::INVPI *
-                         (F(dir_in, n, F_SS90) * F(dir_out, n, F_SS90) * (1 / (std::abs(ndin) + std::abs(ndout)) - R(0.5)) +
-                          R(0.5)) *
-                         ndout;
-            return (1 - subsurface) * f_base + subsurface * f_ss;
-        }
+        case TAKE_MAT_DISNEY_DIFFUSE:  // disney_diffuse.inl:22-46 (body in take_burley.hpp: shared with tag 16)
+            return disney_diffuse_f(eval_texture(m.reflectance, v.uv, sc), m.p0, m.p1, n, dir_in, dir_out);
         case TAKE_MAT_DISNEY_CLEARCOAT:
             // disney_clearcoat.inl:26 returns an uninitialised Vector3{} (vector.h:30); defined here as zero
             // and excluded from the golden tables.

@@ -88,7 +88,7 @@ def device_count():
 
 
 DEBUG_TABLES = {"material": (0, 27, 14), "light": (1, 30, 9), "texture": (2, 6, 3), "to_world": (3, 6, 3),
-                "hemicos": (4, 1, 4)}
+                "hemicos": (4, 1, 4), "burley": (5, 30, 14)}
 
 
 def debug_table(name, inp, rnd, precision=D.TAKE_PRECISION_F64):
@@ -108,12 +108,14 @@ class Scene:
     """A scene resident on the current HIP device: flattened `Scene` + wide BVH in HBM."""
 
     def __init__(self, scene_data, precision=D.TAKE_PRECISION_F32, bvh_threads=0, max_leaf_size=0,
-                 builder=D.TAKE_BUILDER_AUTO):
+                 builder=D.TAKE_BUILDER_AUTO, burley_lobes=False):
+        """burley_lobes: the scene's Disney materials (tags 7..11: Lambert clones, as upstream) are rendered with the
+        real lobes (tags 12..16, an extension — DESIGN.md §4d)"""
         self.sd = scene_data
         self.precision = precision
         self.dtype = np.float64 if precision == D.TAKE_PRECISION_F64 else np.float32
         desc, keep = scene_data.to_desc()
-        opts = D.TakeBuildOpts(precision, bvh_threads, max_leaf_size, builder)
+        opts = D.TakeBuildOpts(precision, bvh_threads, max_leaf_size, builder, 1 if burley_lobes else 0, 0)
         h = C.c_void_p()
         _check(lib().take_hip_scene_create(C.byref(desc), C.byref(opts), C.byref(h)))
         self.h = h
@@ -211,12 +213,12 @@ class SceneGroup:
     C++ host uses in place of its thread pool.  `devices`: HIP device per shard; a device may repeat (logical shards)."""
 
     def __init__(self, scene_data, devices, precision=D.TAKE_PRECISION_F32, bvh_threads=0, max_leaf_size=0,
-                 builder=D.TAKE_BUILDER_AUTO):
+                 builder=D.TAKE_BUILDER_AUTO, burley_lobes=False):
         self.sd = scene_data
         self.precision = precision
         self.dtype = np.float64 if precision == D.TAKE_PRECISION_F64 else np.float32
         desc, keep = scene_data.to_desc()
-        opts = D.TakeBuildOpts(precision, bvh_threads, max_leaf_size, builder)
+        opts = D.TakeBuildOpts(precision, bvh_threads, max_leaf_size, builder, 1 if burley_lobes else 0, 0)
         devs = (C.c_int32 * len(devices))(*devices)
         h = C.c_void_p()
         _check(lib().take_hip_group_create(C.byref(desc), C.byref(opts), len(devices), devs, C.byref(h)))

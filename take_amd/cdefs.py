@@ -11,6 +11,9 @@ TAKE_OK, TAKE_E_INVALID, TAKE_E_DEVICE, TAKE_E_NO_GPU, TAKE_E_NOMEM = 0, -1, -2,
 
 MAT_DIFFUSE, MAT_MIRROR, MAT_PLASTIC, MAT_PHONG, MAT_BLINN_PHONG, MAT_BLINN_PHONG_MICROFACET = range(6)
 MAT_DISNEY_DIFFUSE, MAT_DISNEY_METAL, MAT_DISNEY_GLASS, MAT_DISNEY_CLEARCOAT, MAT_DISNEY_SHEEN, MAT_DISNEY_BSDF = range(6, 12)
+# extension (tags of the real lobes; include/take_hip.h): the Disney tag + 5
+MAT_BURLEY_METAL, MAT_BURLEY_GLASS, MAT_BURLEY_CLEARCOAT, MAT_BURLEY_SHEEN, MAT_BURLEY_BSDF = range(12, 17)
+MATERIAL_PARAMS = 12
 
 
 class TakeTexture(C.Structure):
@@ -19,7 +22,7 @@ class TakeTexture(C.Structure):
 
 
 class TakeMaterial(C.Structure):
-    _fields_ = [("tag", C.c_int32), ("reserved", C.c_int32), ("reflectance", TakeTexture), ("param", c_double4)]
+    _fields_ = [("tag", C.c_int32), ("reserved", C.c_int32), ("reflectance", TakeTexture), ("param", C.c_double * 12)]
 
 
 class TakeImage3(C.Structure):
@@ -64,7 +67,7 @@ class TakeSceneDesc(C.Structure):
 
 class TakeBuildOpts(C.Structure):
     _fields_ = [("precision", C.c_int32), ("bvh_threads", C.c_int32), ("max_leaf_size", C.c_int32),
-                ("builder", C.c_int32)]
+                ("builder", C.c_int32), ("burley_lobes", C.c_int32), ("reserved", C.c_int32)]
 
 
 TAKE_BUILDER_AUTO = 0          # host SAH below 4M shapes, device LBVH from there on

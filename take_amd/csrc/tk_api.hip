@@ -369,7 +369,7 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     const bool want_device = opts.builder == TAKE_BUILDER_DEVICE_LBVH ||
                              (opts.builder == TAKE_BUILDER_AUTO && desc.n_shapes >= TAKE_AUTO_DEVICE_BUILD_SHAPES);
     bool on_device = want_device && sizeof(R) == 4 && desc.n_shapes >= 8 && desc.n_instances == 0;
-    std::string err = prepare_scene<R>(desc, max_leaf, threads, sc.host, on_device ? PREP_TABLES : PREP_ALL);
+    std::string err = prepare_scene<R>(desc, max_leaf, threads, sc.host, on_device ? PREP_TABLES : PREP_ALL, opts.burley_lobes != 0);
     if (!err.empty()) return fail(TAKE_E_INVALID, err);
     clock.lap(on_device ? "host validation + tables" : "host records + SAH build");
     HostScene<R> &h = sc.host;
@@ -385,7 +385,7 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
         }
         if (rc == 1) {  // not buildable on the device (tree too deep): do it on the host after all
             on_device = false;
-            err = prepare_scene<R>(desc, max_leaf, threads, sc.host, PREP_ALL);
+            err = prepare_scene<R>(desc, max_leaf, threads, sc.host, PREP_ALL, opts.burley_lobes != 0);
             if (!err.empty()) return fail(TAKE_E_INVALID, err);
         } else if (rc != TAKE_OK) {
             return rc;
@@ -612,6 +612,11 @@ template <class R> void launch_shade(int tag, const ShadeArgs<R> &a) {
         case 9: launch_shade_tag<R, 9>(a); break;
         case 10: launch_shade_tag<R, 10>(a); break;
         case 11: launch_shade_tag<R, 11>(a); break;
+        case 12: launch_shade_tag<R, 12>(a); break;
+        case 13: launch_shade_tag<R, 13>(a); break;
+        case 14: launch_shade_tag<R, 14>(a); break;
+        case 15: launch_shade_tag<R, 15>(a); break;
+        case 16: launch_shade_tag<R, 16>(a); break;
         default: launch_shade_tag<R, TAG_MISS>(a); break;
     }
 }

@@ -62,6 +62,8 @@ TK_HD float tk_tan(float x) { return tanf(x); }
 TK_HD double tk_tan(double x) { return tan(x); }
 TK_HD float tk_pow(float x, float y) { return powf(x, y); }
 TK_HD double tk_pow(double x, double y) { return pow(x, y); }
+TK_HD float tk_log(float x) { return logf(x); }
+TK_HD double tk_log(double x) { return log(x); }
 TK_HD float tk_acos(float x) { return acosf(x); }
 TK_HD double tk_acos(double x) { return acos(x); }
 TK_HD float tk_atan2(float y, float x) { return atan2f(y, x); }

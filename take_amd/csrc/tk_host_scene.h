@@ -203,7 +203,8 @@ inline bool env_tables(const double *rgb, int w, int h, std::vector<double> &mar
 // 640 MB of records was 470 of the 570 ms of scene_create) — only validation and the small tables happen here.
 enum PrepMode { PREP_ALL = 0, PREP_RECORDS = 1, PREP_TABLES = 2 };
 template <class R>
-std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, HostScene<R> &hs, int mode = PREP_ALL) {
+std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, HostScene<R> &hs, int mode = PREP_ALL,
+                          bool burley_lobes = false) {
     const bool build_bvh = mode == PREP_ALL;
     const bool host_records = mode != PREP_TABLES;
     if (d.camera.width <= 0 || d.camera.height <= 0) return "camera width/height must be positive";
@@ -264,6 +265,8 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
             return "material " + std::to_string(i) + ": bad texture image id";
         MaterialRec<R> &o = hs.materials[i];
         o.tag = m.tag;
+        // TakeBuildOpts.burley_lobes: the reference's Disney alternatives (Lambert clones upstream) get the real lobes
+        if (burley_lobes && m.tag >= TAKE_MAT_DISNEY_METAL && m.tag <= TAKE_MAT_DISNEY_BSDF) o.tag = m.tag + 5;
         o.tex_kind = t.kind;
         o.tex_image = t.image_id;
         o.pad = 0;
@@ -271,7 +274,8 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
         o.uscale = R(t.uscale), o.vscale = R(t.vscale), o.uoffset = R(t.uoffset), o.voffset = R(t.voffset);
         o.p0 = R(m.param[0]);
         o.p1 = R(m.param[1]);
-        tag_used[m.tag] = true;
+        for (int k = 0; k < TAKE_MATERIAL_PARAMS; k++) o.p[k] = R(m.param[k]);
+        tag_used[o.tag] = true;
     }
     hs.n_material_tags = 0;
     hs.tag_mask = 0;

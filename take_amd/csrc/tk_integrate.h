@@ -81,7 +81,7 @@ TK_HD void generate_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, co
 
 constexpr uint32_t REQ_EXTEND = 1, REQ_SHADOW = 2;
 constexpr int TAG_ANY = -1;    // material tag read from the material record
-constexpr int TAG_MISS = 12;   // the segment of the sorted queue holding the paths whose extend ray missed
+constexpr int TAG_MISS = TAKE_MAT_COUNT;   // the segment of the sorted queue holding the paths whose extend ray missed
 
 // One launch round for one path.  `k` is the shade round (uniform over the launch): k = 0 handles the camera
 // ray's hit, k >= 1 finishes loop iteration k-1; iteration k is started when k <= max_depth.

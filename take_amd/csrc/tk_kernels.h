@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(BLOCK) k_pack_exr(const R *__restrict__ rgb, i
 // (tests/golden/tables; column layouts of oracle/ref_harness.cpp).  `rnd` holds, per row, the first draws of the
 // mt19937 stream the reference used, so sampling can be compared value for value.
 namespace tk {
-enum DebugTable { TAB_MATERIAL = 0, TAB_LIGHT = 1, TAB_TEXTURE = 2, TAB_TO_WORLD = 3, TAB_HEMICOS = 4 };
+enum DebugTable { TAB_MATERIAL = 0, TAB_LIGHT = 1, TAB_TEXTURE = 2, TAB_TO_WORLD = 3, TAB_HEMICOS = 4, TAB_BURLEY = 5 };
 constexpr int TAB_RND = 8;
 template <class R>
 __global__ void __launch_bounds__(BLOCK)
@@ -320,6 +320,34 @@ k_debug_table(DeviceScene<R> sc, int kind, const double *__restrict__ in, const 
         }
         o[9] = (double)bsdf_pdf(m, dir_in, dir_out, v);
         put(o + 10, eval_bsdf(sc, m, dir_in, dir_out, R(p[20]), v));
+    } else if (kind == TAB_BURLEY) {
+        // tags 12..16 (rows of oracle_tab_burley): tag, colour[3], param[12], gn[3], sn[3], dir_in[3], dir_out[3],
+        // seed, back -> the material table's 14 output columns
+        const double *p = in + 30 * r;
+        double *o = out + 14 * r;
+        MaterialRec<R> m{};
+        m.tag = (int)p[0];
+        for (int a = 0; a < 3; a++) m.color[a] = R(p[1 + a]);
+        m.uscale = m.vscale = R(1);
+        for (int a = 0; a < TAKE_MATERIAL_PARAMS; a++) m.p[a] = R(p[4 + a]);
+        m.p0 = m.p[0], m.p1 = m.p[1];
+        Isect<R> v{};
+        v.gn = V(p + 16), v.sn = V(p + 19);
+        v.back = p[29] != 0;
+        const Vec3<R> dir_in = V(p + 22), dir_out = V(p + 25);
+        for (int a = 0; a < 14; a++) o[a] = 0.0;
+        BsdfSample<R> rec;
+        const bool ok = sample_bsdf(m, dir_in, v, rng, rec);
+        o[5] = (double)random_real<R>(rng);
+        if (ok) {
+            o[0] = 1.0;
+            put(o + 1, rec.dir_out);
+            o[4] = (double)rec.pdf;
+            put(o + 6, eval_bsdf(sc, m, dir_in, rec.dir_out, rec.pdf, v));
+            o[13] = (double)bsdf_pdf(m, dir_in, rec.dir_out, v);
+        }
+        o[9] = (double)bsdf_pdf(m, dir_in, dir_out, v);
+        put(o + 10, eval_bsdf(sc, m, dir_in, dir_out, R(0), v));
     } else if (kind == TAB_LIGHT) {
         const double *p = in + 30 * r;
         double *o = out + 9 * r;

@@ -104,6 +104,7 @@ template <class R> struct MaterialRec {
     R color[3];
     R uscale, vscale, uoffset, voffset;
     R p0, p1;
+    R p[TAKE_MATERIAL_PARAMS];  // every TakeMaterial::param (the Burley tags read these; p0 = p[0], p1 = p[1])
 };
 struct ImageInfo {
     int32_t width, height;

@@ -17,6 +17,7 @@ template <class R> struct Isect {  // reference `Intersection` (src/intersection
     Vec3<R> pos, gn, sn;
     Vec2<R> uv;
     int32_t material, area_light;
+    bool back;  // gn was flipped to face the ray (not in the reference struct; which side of a dielectric: tk_burley.h)
 };
 
 template <class R> TK_HD Vec3<R> ld3(const R *p) { return {p[0], p[1], p[2]}; }
@@ -37,6 +38,7 @@ TK_HD void make_isect(const DeviceScene<R> &sc, Vec3<R> ro, Vec3<R> rd, int32_t 
     out.pos = ro + rd * t;
     if ((p.meta & 0xff) == PRIM_SPHERE) {
         Vec3<R> n = normalize(out.pos - Vec3<R>{p.a[0], p.a[1], p.a[2]});
+        out.back = !(dot(rd, n) < R(0));
         n = dot(rd, n) < R(0) ? n : -n;
         out.gn = n;
         out.sn = n;
@@ -54,6 +56,7 @@ TK_HD void make_isect(const DeviceScene<R> &sc, Vec3<R> ro, Vec3<R> rd, int32_t 
         out.material = is.material;
     }
     Vec3<R> gn = normalize(cross(e1, e2));
+    out.back = !(dot(rd, gn) < R(0));
     gn = dot(rd, gn) < R(0) ? gn : -gn;
     out.gn = gn;
     out.uv = {u, v};
@@ -214,11 +217,18 @@ template <class R> TK_HD BsdfSample<R> cosine_sample(Vec3<R> n, const Isect<R> &
     return s;
 }
 
+}  // namespace tk
+#include "tk_burley.h"  // tags 12..16
+namespace tk {
+
 // TAG: the material tag as a compile-time constant (the shade kernels are instantiated per tag and launched over
 // the tag's segment of the material-sorted queue, so the 12-way dispatch folds away); TAG = -1 reads m.tag.
 // returns false when the reference returns an empty optional (dir_in below the geometric surface)
 template <class R, int TAG = -1, class G>
 TK_HD bool sample_bsdf(const MaterialRec<R> &m, Vec3<R> dir_in, const Isect<R> &v, G &rng, BsdfSample<R> &out) {
+    if constexpr (TAG < 0 || tag_is_burley(TAG)) {
+        if (tag_is_burley(TAG >= 0 ? TAG : m.tag)) return burley_sample<R, TAG>(m, dir_in, v, rng, out);
+    }
     if (dot(v.gn, dir_in) < R(0)) return false;
     const Vec3<R> n = facing(dir_in, v);
     const int tag = TAG >= 0 ? TAG : m.tag;
@@ -271,6 +281,9 @@ TK_HD bool sample_bsdf(const MaterialRec<R> &m, Vec3<R> dir_in, const Isect<R> &
 template <class R, int TAG = -1>
 TK_HD R bsdf_pdf(const MaterialRec<R> &m, Vec3<R> dir_in, Vec3<R> dir_out, const Isect<R> &v) {
     const int tag = TAG >= 0 ? TAG : m.tag;
+    if constexpr (TAG < 0 || tag_is_burley(TAG)) {
+        if (tag_is_burley(tag)) return burley_pdf<R, TAG>(m, dir_in, dir_out, v);
+    }
     if (tag == 1) return R(0);
     if (dot(v.gn, dir_out) < R(0)) return R(0);
     const Vec3<R> n = facing(dir_in, v);
@@ -302,6 +315,9 @@ template <class R, int TAG = -1>
 TK_HD Vec3<R> eval_bsdf(const DeviceScene<R> &sc, const MaterialRec<R> &m, Vec3<R> dir_in, Vec3<R> dir_out, R rec_pdf,
                         const Isect<R> &v) {
     const Vec3<R> zero{R(0), R(0), R(0)};
+    if constexpr (TAG < 0 || tag_is_burley(TAG)) {
+        if (tag_is_burley(TAG >= 0 ? TAG : m.tag)) return burley_eval<R, TAG>(sc, m, dir_in, dir_out, v);
+    }
     if (dot(v.gn, dir_in) < R(0) || dot(v.gn, dir_out) < R(0)) return zero;
     const Vec3<R> n = facing(dir_in, v);
     const int tag = TAG >= 0 ? TAG : m.tag;
@@ -338,21 +354,8 @@ TK_HD Vec3<R> eval_bsdf(const DeviceScene<R> &sc, const MaterialRec<R> &m, Vec3<
             R G = g_hat(dir_out, n, m.p0) * g_hat(dir_in, n, m.p0);
             return Fh * Dh * G * R(0.25) / dot(n, dir_in);
         }
-        case 6: {  // DisneyDiffuse, src/materials/disney_diffuse.inl:22-46
-            Vec3<R> h = normalize(dir_in + dir_out);
-            R hdout = dot(h, dir_out), ndout = dot(n, dir_out), ndin = dot(n, dir_in);
-            Vec3<R> Kd = eval_texture(sc, m, v.uv);
-            R fd90 = R(0.5) + R(2) * m.p0 * hdout * hdout;
-            R fi = R(1) + (fd90 - R(1)) * tk_pow(R(1) - dot(n, dir_in), R(5));
-            R fo = R(1) + (fd90 - R(1)) * tk_pow(R(1) - dot(n, dir_out), R(5));
-            Vec3<R> base = Kd * Const<R>::INVPI * fi * fo * ndout;
-            R fss90 = m.p0 * hdout * hdout;
-            R si = R(1) + (fss90 - R(1)) * tk_pow(R(1) - dot(n, dir_in), R(5));
-            R so = R(1) + (fss90 - R(1)) * tk_pow(R(1) - dot(n, dir_out), R(5));
-            Vec3<R> ss = R(1.25) * Kd * Const<R>::INVPI *
-                         (si * so * (R(1) / (tk_fabs(ndin) + tk_fabs(ndout)) - R(0.5)) + R(0.5)) * ndout;
-            return (R(1) - m.p1) * base + m.p1 * ss;
-        }
+        case 6:  // DisneyDiffuse, src/materials/disney_diffuse.inl:22-46 (body in tk_burley.h: shared with tag 16)
+            return disney_diffuse_value(eval_texture(sc, m, v.uv), m.p0, m.p1, n, dir_in, dir_out);
         case 9:  // DisneyClearcoat: the reference returns an uninitialised value; defined as zero
             return zero;
         default: {

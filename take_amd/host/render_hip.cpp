@@ -70,6 +70,8 @@ Image3 render(const std::vector<std::string> &params) {
     const bool f64 = prec && std::string(prec) == "f64";
     TakeBuildOpts bo{};
     bo.precision = f64 ? TAKE_PRECISION_F64 : TAKE_PRECISION_F32;
+    // TAKE_HIP_BURLEY=1: the scene's disney* materials get real lobes instead of upstream's Lambert clones (extension)
+    if (const char *b = std::getenv("TAKE_HIP_BURLEY")) bo.burley_lobes = std::atoi(b) != 0;
     // TAKE_HIP_GPUS: "<n>" or "<n>:<device>" (all shards on one device)
     int n_gpus = 1, one_device = -1;
     if (const char *g = std::getenv("TAKE_HIP_GPUS")) {

@@ -64,17 +64,33 @@ template <class TextureT> inline TakeTexture flatten_texture(const TextureT &t) 
     return out;
 }
 
-// members are probed by name with `if constexpr` so one visitor serves all 12 alternatives
+// members are probed by name so one visitor serves all 12 alternatives: member_<name>(alt) is the member's value,
+// or 0 where the alternative has no such member
 template <class M, class = void> struct has_reflectance : std::false_type {};
 template <class M> struct has_reflectance<M, std::void_t<decltype(std::declval<M>().reflectance)>> : std::true_type {};
-template <class M, class = void> struct has_eta : std::false_type {};
-template <class M> struct has_eta<M, std::void_t<decltype(std::declval<M>().eta)>> : std::true_type {};
-template <class M, class = void> struct has_exponent : std::false_type {};
-template <class M> struct has_exponent<M, std::void_t<decltype(std::declval<M>().exponent)>> : std::true_type {};
-template <class M, class = void> struct has_roughness : std::false_type {};
-template <class M> struct has_roughness<M, std::void_t<decltype(std::declval<M>().roughness)>> : std::true_type {};
-template <class M, class = void> struct has_subsurface : std::false_type {};
-template <class M> struct has_subsurface<M, std::void_t<decltype(std::declval<M>().subsurface)>> : std::true_type {};
+#define TAKE_HIP_MEMBER_PROBE(name)                                                                          \
+    template <class M, class = void> struct has_##name : std::false_type {};                                   \
+    template <class M> struct has_##name<M, std::void_t<decltype(std::declval<M>().name)>> : std::true_type {}; \
+    template <class M> inline double member_##name(const M &m) {                                               \
+        if constexpr (has_##name<M>::value)                                                                    \
+            return double(m.name);                                                                             \
+        else                                                                                                   \
+            return 0.0;                                                                                        \
+    }
+TAKE_HIP_MEMBER_PROBE(eta)
+TAKE_HIP_MEMBER_PROBE(exponent)
+TAKE_HIP_MEMBER_PROBE(roughness)
+TAKE_HIP_MEMBER_PROBE(subsurface)
+TAKE_HIP_MEMBER_PROBE(anisotropic)
+TAKE_HIP_MEMBER_PROBE(clearcoat_gloss)
+TAKE_HIP_MEMBER_PROBE(sheen_tint)
+TAKE_HIP_MEMBER_PROBE(specular_transmission)
+TAKE_HIP_MEMBER_PROBE(metallic)
+TAKE_HIP_MEMBER_PROBE(specular)
+TAKE_HIP_MEMBER_PROBE(specular_tint)
+TAKE_HIP_MEMBER_PROBE(sheen)
+TAKE_HIP_MEMBER_PROBE(clearcoat)
+#undef TAKE_HIP_MEMBER_PROBE
 
 }  // namespace detail
 
@@ -159,15 +175,34 @@ template <class SceneT> inline void flatten_scene(const SceneT &scene, FlatScene
             [&](const auto &alt) {
                 using A = std::decay_t<decltype(alt)>;
                 if constexpr (has_reflectance<A>::value) tm.reflectance = flatten_texture(alt.reflectance);
-                if constexpr (has_eta<A>::value) tm.param[0] = alt.eta;
-                if constexpr (has_exponent<A>::value) tm.param[0] = alt.exponent;
-                if constexpr (has_roughness<A>::value && has_subsurface<A>::value) {
-                    tm.param[0] = alt.roughness;
-                    tm.param[1] = alt.subsurface;
+                // TakeMaterial::param = the alternative's scalar members in declaration order (src/material.h:7-80)
+                double *p = tm.param;
+                switch (tm.tag) {
+                    case TAKE_MAT_MIRROR:
+                    case TAKE_MAT_PLASTIC: p[0] = member_eta(alt); break;
+                    case TAKE_MAT_PHONG:
+                    case TAKE_MAT_BLINN_PHONG:
+                    case TAKE_MAT_BLINN_PHONG_MICROFACET: p[0] = member_exponent(alt); break;
+                    case TAKE_MAT_DISNEY_DIFFUSE: p[0] = member_roughness(alt), p[1] = member_subsurface(alt); break;
+                    case TAKE_MAT_DISNEY_METAL: p[0] = member_roughness(alt), p[1] = member_anisotropic(alt); break;
+                    case TAKE_MAT_DISNEY_GLASS:
+                        p[0] = member_roughness(alt), p[1] = member_anisotropic(alt), p[2] = member_eta(alt);
+                        break;
+                    case TAKE_MAT_DISNEY_CLEARCOAT: p[0] = member_clearcoat_gloss(alt); break;
+                    case TAKE_MAT_DISNEY_SHEEN: p[0] = member_sheen_tint(alt); break;
+                    case TAKE_MAT_DISNEY_BSDF:
+                        p[0] = member_specular_transmission(alt), p[1] = member_metallic(alt);
+                        p[2] = member_subsurface(alt), p[3] = member_specular(alt), p[4] = member_roughness(alt);
+                        p[5] = member_specular_tint(alt), p[6] = member_anisotropic(alt), p[7] = member_sheen(alt);
+                        p[8] = member_sheen_tint(alt), p[9] = member_clearcoat(alt);
+                        p[10] = member_clearcoat_gloss(alt), p[11] = member_eta(alt);
+                        break;
+                    default: break;
                 }
             },
             m);
-        // only Mirror/Plastic read eta, only DisneyDiffuse reads roughness/subsurface on the path
+        // tags 7..11 carry their parameters although the reference's lobes (and tags 7..11 here) ignore them:
+        // TakeBuildOpts.burley_lobes turns them into tags 12..16, which read them
         out.materials.push_back(tm);
     }
 

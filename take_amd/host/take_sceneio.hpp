@@ -12,8 +12,8 @@
 //   i32 n_spheres;   per sphere: f64 center[3], radius; i32 material_id, 0
 //   i64 n_shapes;    i32 kind[n], ref[n], face[n], area_light[n]
 //   i32 n_lights;    per light: i32 kind, shape_id; f64 intensity[3], position[3]
-//   i32 n_materials; per material: i32 tag, tex_kind, tex_image, 0;
-//                              f64 value[3], uscale, vscale, uoffset, voffset, param[4]
+//   i32 n_materials; per material: i32 tag, tex_kind, tex_image, n_more (0 or 8);
+//                              f64 value[3], uscale, vscale, uoffset, voffset, param[4], param[4 .. 4 + n_more)
 //   i32 n_images;    per image: i32 w, h; f64 data[w*h*3]
 #pragma once
 
@@ -97,13 +97,15 @@ inline void write_tkscene(const std::string &path, const TakeSceneDesc &d, int s
         w.i32(m.tag);
         w.i32(m.reflectance.kind);
         w.i32(m.reflectance.image_id);
-        w.i32(0);
+        bool more = false;  // files of scenes without Disney parameters stay byte-identical to the first format
+        for (int k = 4; k < TAKE_MATERIAL_PARAMS; k++) more = more || m.param[k] != 0.0;
+        w.i32(more ? TAKE_MATERIAL_PARAMS - 4 : 0);
         w.f64n(m.reflectance.value, 3);
         w.f64(m.reflectance.uscale);
         w.f64(m.reflectance.vscale);
         w.f64(m.reflectance.uoffset);
         w.f64(m.reflectance.voffset);
-        w.f64n(m.param, 4);
+        w.f64n(m.param, more ? TAKE_MATERIAL_PARAMS : 4);
     }
     w.i32(d.n_images);
     for (int i = 0; i < d.n_images; i++) {

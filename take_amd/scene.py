@@ -45,7 +45,7 @@ class Material:
     tex_kind: int = 0
     tex_image: int = 0
     uvxf: tuple = (1.0, 1.0, 0.0, 0.0)  # uscale, vscale, uoffset, voffset
-    param: tuple = (0.0, 0.0, 0.0, 0.0)
+    param: tuple = (0.0,) * 12  # TakeMaterial::param
 
 
 @dataclass
@@ -164,7 +164,7 @@ class SceneData:
 
     def add_material(self, tag, color=(0.5, 0.5, 0.5), param=(0.0, 0.0, 0.0, 0.0), tex_image=None,
                      uvxf=(1.0, 1.0, 0.0, 0.0)):
-        p = tuple(param) + (0.0,) * (4 - len(param))
+        p = tuple(float(x) for x in param) + (0.0,) * (12 - len(param))
         self.materials.append(Material(int(tag), tuple(color), 0 if tex_image is None else 1,
                                        0 if tex_image is None else int(tex_image), tuple(uvxf), p))
         return len(self.materials) - 1
@@ -221,7 +221,7 @@ class SceneData:
             mats[i].reflectance.value = D.c_double3(*m.color)
             (mats[i].reflectance.uscale, mats[i].reflectance.vscale, mats[i].reflectance.uoffset,
              mats[i].reflectance.voffset) = m.uvxf
-            mats[i].param = D.c_double4(*m.param)
+            mats[i].param = (C.c_double * 12)(*(tuple(m.param) + (0.0,) * (12 - len(m.param))))
         images = (D.TakeImage3 * max(len(self.images), 1))()
         for i, im in enumerate(self.images):
             a = np.ascontiguousarray(im, np.float64)
@@ -295,10 +295,10 @@ def load_tkscene(path) -> SceneData:
         kind, sid = r.take("ii")
         s.lights.append(Light(kind, sid, tuple(r.arr("<f8", 3)), tuple(r.arr("<f8", 3))))
     for _ in range(r.take("i")):
-        tag, tk, ti, _pad = r.take("iiii")
+        tag, tk, ti, n_more = r.take("iiii")
         col = tuple(r.arr("<f8", 3))
         uvxf = tuple(r.arr("<f8", 4))
-        par = tuple(r.arr("<f8", 4))
+        par = tuple(r.arr("<f8", 4 + n_more)) + (0.0,) * (8 - n_more)
         s.materials.append(Material(tag, col, tk, ti, uvxf, par))
     for _ in range(r.take("i")):
         w, h = r.take("ii")
@@ -339,10 +339,12 @@ def save_tkscene(path, s: SceneData):
             f.write(np.asarray(l.position, "<f8").tobytes())
         f.write(struct.pack("<i", len(s.materials)))
         for m in s.materials:
-            f.write(struct.pack("<iiii", m.tag, m.tex_kind, m.tex_image, 0))
+            par = tuple(m.param) + (0.0,) * (12 - len(m.param))
+            n_more = 8 if any(par[4:]) else 0  # scenes without Disney parameters keep the first format's bytes
+            f.write(struct.pack("<iiii", m.tag, m.tex_kind, m.tex_image, n_more))
             f.write(np.asarray(m.color, "<f8").tobytes())
             f.write(np.asarray(m.uvxf, "<f8").tobytes())
-            f.write(np.asarray(m.param, "<f8").tobytes())
+            f.write(np.asarray(par[:4 + n_more], "<f8").tobytes())
         f.write(struct.pack("<i", len(s.images)))
         for im in s.images:
             f.write(struct.pack("<ii", im.shape[1], im.shape[0]))

@@ -6,6 +6,7 @@ mirrors src/scene.h): rectangles are the parser's 2x2 quads with vertex normals 
 (src/parse/parse_scene.cpp:891-927), the soup is a mesh with unshared vertices and face normals
 (`faceNormals=true`: no vertex-normal array), the light is an emissive rectangle = two DiffuseAreaLights.
 """
+import dataclasses
 import math
 
 import numpy as np
@@ -141,6 +142,78 @@ def instanced_scene(n_instances, tris_per_mesh, width, height, spp, seed=4321, m
     for i in range(n_instances):
         sd.add_instance(mesh, np.concatenate([rot[i], trans[i][:, None]], axis=1), mats[i % len(mats)])
     return sd.flattened() if flatten else sd
+
+
+BURLEY_BSDF_ORDER = ("specular_transmission", "metallic", "subsurface", "specular", "roughness", "specular_tint",
+                     "anisotropic", "sheen", "sheen_tint", "clearcoat", "clearcoat_gloss", "eta")
+
+
+def principled(**kw):
+    """TakeMaterial.param of a DisneyBSDF / BURLEY_BSDF material (defaults: the reference parser's,
+    src/parse/parse_scene.cpp:635-700)"""
+    d = dict(specular_transmission=0.0, metallic=0.0, subsurface=0.0, specular=0.5, roughness=0.5, specular_tint=0.0,
+             anisotropic=0.0, sheen=0.0, sheen_tint=0.5, clearcoat=0.0, clearcoat_gloss=1.0, eta=1.5)
+    d.update(kw)
+    return tuple(float(d[k]) for k in BURLEY_BSDF_ORDER)
+
+
+def _cube(center, half):
+    """closed box with outward-wound faces, no vertex normals (so the geometric orientation decides front / back)"""
+    c = np.asarray(center, np.float64)
+    v = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], np.float64) * half + c
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    idx = []
+    for a, b, cc, d in quads:
+        idx += [[a, b, cc], [a, cc, d]]
+    return v, np.array(idx, np.int32)
+
+
+def burley_scene(width=96, height=96, spp=8, real=True, max_depth=8):
+    """A Cornell-style box holding one object per Disney material — metal (anisotropic) sphere, glass sphere, glass
+    cube (triangle back faces), sheen sphere, two principled spheres (one transmissive with clearcoat, one metallic
+    and tinted) and a clearcoat-only sphere.  real=True uses tags 12..16 (the Burley lobes); real=False uses the
+    reference's tags 7..11 with the same parameters (Lambert clones upstream; TakeBuildOpts.burley_lobes maps them
+    to the former)."""
+    from . import cdefs as D
+
+    sd = SceneData(width=width, height=height, lookfrom=(0.0, 0.0, 3.4), lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0),
+                   vfov=38.0, background=(0.0, 0.0, 0.0), spp=spp, max_depth=max_depth)
+    white = sd.add_material(D.MAT_DIFFUSE, (0.73, 0.73, 0.73))
+    red = sd.add_material(D.MAT_DIFFUSE, (0.65, 0.05, 0.05))
+    green = sd.add_material(D.MAT_DIFFUSE, (0.12, 0.45, 0.15))
+    box_with_light(sd, white, red, green, light_half=0.35)
+    off = 5 if real else 0
+    metal = sd.add_material(D.MAT_DISNEY_METAL + off, (0.95, 0.64, 0.54), (0.35, 0.7))
+    glass = sd.add_material(D.MAT_DISNEY_GLASS + off, (0.95, 0.97, 1.0), (0.15, 0.0, 1.5))
+    glass2 = sd.add_material(D.MAT_DISNEY_GLASS + off, (1.0, 0.85, 0.7), (0.3, 0.4, 1.33))
+    coat = sd.add_material(D.MAT_DISNEY_CLEARCOAT + off, (0.0, 0.0, 0.0), (0.6,))
+    sheen = sd.add_material(D.MAT_DISNEY_SHEEN + off, (0.3, 0.5, 0.9), (0.7,))
+    pr1 = sd.add_material(D.MAT_DISNEY_BSDF + off, (0.8, 0.3, 0.2),
+                          principled(specular_transmission=0.6, roughness=0.25, clearcoat=0.8, clearcoat_gloss=0.5,
+                                     sheen=0.4, eta=1.45))
+    pr2 = sd.add_material(D.MAT_DISNEY_BSDF + off, (0.9, 0.75, 0.3),
+                          principled(metallic=0.8, roughness=0.4, anisotropic=0.6, specular_tint=0.5, subsurface=0.3))
+    sd.add_sphere((-0.6, -0.69, -0.3), 0.3, metal)
+    sd.add_sphere((0.1, -0.67, 0.35), 0.32, glass)
+    sd.add_sphere((0.65, -0.74, -0.35), 0.25, sheen)
+    sd.add_sphere((-0.55, 0.0, -0.55), 0.27, pr1)
+    sd.add_sphere((0.55, 0.05, -0.5), 0.27, pr2)
+    sd.add_sphere((0.0, 0.45, -0.6), 0.2, coat)
+    pos, idx = _cube((-0.15, -0.79, -0.5), 0.2)  # nothing coincides with the floor (exact ties: DESIGN.md §6)
+    sd.add_mesh(pos, idx, glass2)
+    return sd
+
+
+def with_burley_lobes(sd: SceneData):
+    """copy of `sd` whose Disney materials (tags 7..11) carry the tags of the real lobes (12..16) — what
+    TakeBuildOpts.burley_lobes does inside take_hip_scene_create"""
+    import copy
+    from . import cdefs as D
+
+    out = copy.copy(sd)
+    out.materials = [dataclasses.replace(m, tag=m.tag + 5) if D.MAT_DISNEY_METAL <= m.tag <= D.MAT_DISNEY_BSDF else m
+                     for m in sd.materials]
+    return out
 
 
 def write_reference_inputs(sd: SceneData, directory, name="scene"):
