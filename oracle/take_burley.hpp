@@ -153,7 +153,9 @@ template <class R> inline V3<R> glass_f(V3<R> base, V3<R> wi, V3<R> wo, bool ref
     R DG = ggx_d(h, ax, ay) * smith_g1(wi, ax, ay) * smith_g1(V3<R>{wo.x, wo.y, std::abs(wo.z)}, ax, ay);
     if (reflect) return base * (F * DG / (R(4) * wi.z));
     R denom = hi + eta * ho;
-    V3<R> root{std::sqrt(base.x), std::sqrt(base.y), std::sqrt(base.z)};
+    // max(0, .): the reference's bilinear filter extrapolates at the wrap seam (src/texture.cpp:13-24), so a textured
+    // base colour can be slightly negative
+    V3<R> root{std::sqrt(std::fmax(R(0), base.x)), std::sqrt(std::fmax(R(0), base.y)), std::sqrt(std::fmax(R(0), base.z))};
     return root * ((R(1) - F) * DG * std::abs(ho * hi) / (wi.z * denom * denom));
 }
 template <class R> inline R glass_pdf(V3<R> wi, V3<R> wo, bool reflect, R eta, R ax, R ay) {

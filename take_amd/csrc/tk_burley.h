@@ -197,7 +197,8 @@ template <class R> TK_HD GlassTerm<R> glass_term(const BurleyFrame<R> &f, Vec3<R
     return g;
 }
 template <class R> TK_HD Vec3<R> glass_colour(Vec3<R> base, bool upper) {
-    return upper ? base : Vec3<R>{tk_sqrt(base.x), tk_sqrt(base.y), tk_sqrt(base.z)};
+    // max(0, .): a textured base colour can be slightly negative (the reference's filter extrapolates at the wrap seam)
+    return upper ? base : Vec3<R>{tk_sqrt(tk_fmax(R(0), base.x)), tk_sqrt(tk_fmax(R(0), base.y)), tk_sqrt(tk_fmax(R(0), base.z))};
 }
 
 // sampling weights of the principled material: diffuse | metal | glass | clearcoat

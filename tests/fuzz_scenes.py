@@ -1,6 +1,7 @@
 """Randomised scenes for the fuzz tests (tests/test_fuzz_scenes.py): every feature of the scene model at once, with the
 degenerate inputs a parser can hand over — zero-area and needle triangles, duplicated triangles, a triangle seen
-edge-on, nested and tiny spheres, all 12 material tags with random parameters, an image texture, emissive quads (with
+edge-on, nested and tiny spheres, all 17 material tags (the 12 of the reference + the 5 Burley lobes) with random
+parameters, an image texture, emissive quads (with
 vertex normals, as the reference requires), a sphere light, a point light, any scale from 1e-3 to 1e3."""
 import numpy as np
 
@@ -27,6 +28,19 @@ def random_scene(seed, res=24):
                                     tex_image=0 if rng.uniform() < 0.3 else None,
                                     uvxf=(float(rng.uniform(0.5, 3)), float(rng.uniform(0.5, 3)), float(rng.uniform(0, 1)),
                                           float(rng.uniform(0, 1)))))
+    # the Burley lobes (tags 12..16) from a second stream, so that the geometry of a seed does not depend on them; about
+    # a third of the material picks below are redirected to one of them
+    rng2 = np.random.default_rng(seed + 100003)
+    for tag in range(12, 17):
+        p = rng2.uniform(0, 1, 12)
+        if tag == D.MAT_BURLEY_GLASS:
+            p[2] = rng2.uniform(1.1, 2.0)
+        p[11] = rng2.uniform(1.1, 2.0)
+        mats.append(sd.add_material(tag, tuple(rng2.uniform(0.1, 0.95, 3)), tuple(float(x) for x in p),
+                                    tex_image=0 if rng2.uniform() < 0.3 else None,
+                                    uvxf=(float(rng2.uniform(0.5, 3)), float(rng2.uniform(0.5, 3)), 0.25, 0.5)))
+    reference_mats = list(mats[:12])
+    mats = [m if rng2.uniform() > 0.35 else mats[12 + int(rng2.integers(0, 5))] for m in reference_mats]
     # a floor and a back wall so that paths bounce
     for c, ux, uy, n in (((0, -1, 0), (1.5, 0, 0), (0, 0, -1.5), (0, 1, 0)), ((0, 0, -1.2), (1.5, 0, 0), (0, 1.5, 0), (0, 0, 1))):
         pos, idx, nrm, uv = scenes._quad(c, ux, uy, n)
