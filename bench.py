@@ -309,7 +309,7 @@ def main():
     if rank == 0:
         samples = args.width * args.height * spp_total * args.steps
         value = samples / elapsed / 1e6
-        # dominant kernel: tk::k_trace_group<float, 2, false, false, PathIo<float>> (closest hit).  achieved = algorithmic bytes per launch
+        # dominant kernel: tk::k_trace_group<float, 1, false, false, PathIo<float>> (closest hit).  achieved = algorithmic bytes per launch
         # / average launch duration, both over the timed region (HIP events recorded on the render stream)
         n_launch = max(acc["launches_trace_closest"], 1)
         avg_ms = acc["ms_trace_closest"] / n_launch
@@ -342,7 +342,7 @@ def main():
                          "achieved_is": "algorithmic bytes (node_visits x node bytes + prim_tests x 48 B + ray state) per "
                                         "launch / launch time; mostly served by L2 / Infinity Cache — the kernel is "
                                         "VALU-issue-bound (DESIGN.md §7), `traffic` is what reaches the fabric",
-                         "kernel": f"tk::k_trace_group<{'double' if f64_main else 'float'},2,false,false,PathIo<..>,true> (closest hit, pair kernel, compressed nodes)", "launches": n_launch,
+                         "kernel": f"tk::k_trace_group<{'double' if f64_main else 'float'},1,false,false,PathIo<..>,true> (closest hit, one ray per lane, compressed nodes)", "launches": n_launch,
                          "avg_launch_ms": avg_ms, "bytes_per_ray": bytes_per_ray,
                          "rays_per_launch": acc["rays_closest"] / n_launch},
         }

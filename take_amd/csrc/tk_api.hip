@@ -129,7 +129,7 @@ template <class R> struct SceneT {
     DevBuf<unsigned long long> spill;
     int64_t capacity = 0;  // path slots allocated
     int trace_grid = 0;
-    int group = 2;             // lanes per ray of the trace kernel (the pair kernel is the only instance)
+    int group = TQ_GROUP;      // lanes per ray of the trace kernel (one instantiated size)
     bool built_on_device = false;
     int64_t spill_stride = 0;  // ray groups in the persistent trace grid
 
@@ -359,8 +359,10 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     if (threads <= 0) threads = 1;
     int max_leaf = opts.max_leaf_size;
     if (max_leaf <= 0 && std::getenv("TAKE_HIP_MAX_LEAF")) max_leaf = std::atoi(std::getenv("TAKE_HIP_MAX_LEAF"));  // tuning knob
-    sc.group = 2;  // pair traversal: measured fastest on MI355X (round 1: quad 143.6, pair 121.5, one ray per lane 128.8 ms
-                   // of closest-hit time per 8.3 M samples); the other group sizes of the template are no longer instantiated
+    // lanes per ray: one (TQ_GROUP).  Round 1 measured quad 143.6 / pair 121.5 / one ray per lane 128.8 ms of closest-hit
+    // time per 8.3 M samples on full-width nodes; on the 64-byte nodes one ray per lane is 9 % (f32) and 22 % (f64)
+    // ahead of the pair kernel.  The other group sizes stay behind -DTQ_GROUP for comparison builds.
+    sc.group = TQ_GROUP;
     const char *fmt_env = std::getenv("TAKE_HIP_NODES");
     const std::string fmt = fmt_env ? fmt_env : "";
     // device build: f32 scenes with enough primitives to make a tree; otherwise (and as its fall-back) the host SAH build
@@ -379,7 +381,7 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
         if constexpr (sizeof(R) == 4) {
             rc = make_prims_on_device(sc, desc);
             clock.lap("mesh arrays -> HBM, records");
-            if (!rc) rc = build_bvh_device(sc, max_leaf, sc.group == 2 && fmt != "wide", fmt == "q16");
+            if (!rc) rc = build_bvh_device(sc, max_leaf, sc.group <= 2 && fmt != "wide", fmt == "q16");
         } else {
             rc = 1;
         }
@@ -398,7 +400,7 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
         clock.lap("primitive records -> HBM");
     }
     if (!on_device) {
-        use_q = sc.group == 2 && !h.qnodes.empty();  // compressed nodes: f32 pair kernel
+        use_q = sc.group <= 2 && !h.qnodes.empty();  // compressed nodes (not in the quad kernel)
         if (use_q) HIP_TRY(sc.qnodes.upload(h.qnodes));
         else HIP_TRY(sc.nodes.upload(h.nodes));
     }
@@ -458,12 +460,12 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     HIP_TRY(hipMemset(sc.counters.p, 0, sc.counters.bytes()));
     // persistent trace grid: resident blocks of the heaviest trace kernel x CUs
     int per_cu = 0;
-    const int groups_per_block = GroupGeom<2>::GROUPS, spill_levels = GroupGeom<2>::SPILL;
-    if (use_q) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>, true>, TQ_BLOCK, 0));
-    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>>, TQ_BLOCK, 0));
+    const int groups_per_block = GroupGeom<TQ_GROUP>::GROUPS, spill_levels = GroupGeom<TQ_GROUP>::SPILL;
+    if (use_q) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, TQ_GROUP, false, false, PathIo<R>, true>, TQ_BLOCK, 0));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, TQ_GROUP, false, false, PathIo<R>>, TQ_BLOCK, 0));
     if (sc.inst_trace.n) {  // two-level scenes run the INST instances: size the persistent grid for them
-        if (use_q) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>, true, true>, TQ_BLOCK, 0));
-        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 2, false, false, PathIo<R>, false, true>, TQ_BLOCK, 0));
+        if (use_q) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, TQ_GROUP, false, false, PathIo<R>, true, true>, TQ_BLOCK, 0));
+        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, TQ_GROUP, false, false, PathIo<R>, false, true>, TQ_BLOCK, 0));
     }
     per_cu = std::max(1, std::min(per_cu, 8));
     if (const char *e = std::getenv("TAKE_HIP_TRACE_BLOCKS")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));  // experiment: leave room for a concurrent kernel
@@ -558,7 +560,7 @@ void launch_trace(int group, bool any, bool count, dim3 grid, hipStream_t stream
                   const int32_t *n_ptr, int32_t n_direct, int32_t *head, unsigned long long *counters, int counter_word,
                   StackSpill spill) {
 #define TK_LAUNCH(A, C, Q, I)                                                                                              \
-    hipLaunchKernelGGL((k_trace_group<R, 2, A, C, Io, Q, I>), grid, dim3(TQ_BLOCK), 0, stream, dev, io, n_ptr, n_direct, head, \
+    hipLaunchKernelGGL((k_trace_group<R, TQ_GROUP, A, C, Io, Q, I>), grid, dim3(TQ_BLOCK), 0, stream, dev, io, n_ptr, n_direct, head, \
                        counters, counter_word, spill)
 #define TK_LAUNCH_AC(Q, I)                          \
     do {                                            \
@@ -567,7 +569,7 @@ void launch_trace(int group, bool any, bool count, dim3 grid, hipStream_t stream
         else if (count) TK_LAUNCH(false, true, Q, I);        \
         else TK_LAUNCH(false, false, Q, I);                  \
     } while (0)
-    (void)group;  // pair kernel only
+    (void)group;  // one instantiated group size (TQ_GROUP)
     const bool q = dev.qnodes != nullptr, two_level = dev.inst_trace != nullptr;
     if (q && two_level) TK_LAUNCH_AC(true, true);
     else if (q) TK_LAUNCH_AC(true, false);

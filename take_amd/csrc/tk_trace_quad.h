@@ -27,17 +27,29 @@
 namespace tk {
 
 // tuning knobs (overridable with -D for experiments)
+#ifndef TQ_GROUP
+#define TQ_GROUP 1  // lanes per ray of the instantiated kernels: 1 = one ray per lane (production), 2 = pair, 4 = quad
+#endif
 #ifndef TQ_MIN_WAVES
-#define TQ_MIN_WAVES 6  // register cap for 6 waves per SIMD: measured +4 % on the pair kernel (7 and 8 spill and lose)
+// register cap in waves per SIMD.  One ray per lane: 92 VGPRs = 5 waves (6 caps at 80 and changes nothing measurable);
+// pair: 6 (measured +4 % over 5; 7 and 8 spill and lose)
+#define TQ_MIN_WAVES (TQ_GROUP == 1 ? 5 : 6)
 #endif
 #ifndef TQ_F64_WAVES
 #define TQ_F64_WAVES 4  // register cap of the f64 instances (waves per SIMD)
+#endif
+#ifndef TQ_G1_LEVELS
+// stack levels in LDS with one ray per lane: 15 x 260 entries x 8 B = 31 KB per block = the five blocks per CU the
+// registers allow (measured: 8 levels -13 %, 12 and 15 equal, 16 at four blocks -5 %)
+#define TQ_G1_LEVELS 15
 #endif
 #ifndef TQ_PAIR_LEVELS
 #define TQ_PAIR_LEVELS 24
 #endif
 #ifndef TQ_SWITCH_LANES
-#define TQ_SWITCH_LANES 32  // leave the node phase when fewer lanes than this (of 64) are at interior nodes
+// leave the node phase when fewer lanes than this (of 64) are at interior nodes (one ray per lane: 16 / 24 / 32 / 40
+// within 1 %; pair: 32)
+#define TQ_SWITCH_LANES (TQ_GROUP == 1 ? 24 : 32)
 #endif
 #ifndef TQ_REFILL_DIV
 #define TQ_REFILL_DIV 8     // refill when at least 1/TQ_REFILL_DIV of the wave's ray slots are idle (4: -2 %, measured)
@@ -175,7 +187,7 @@ template <int G> struct GroupGeom {
     static constexpr int CPL = 4 / G;                    // child slots per lane
     static constexpr int GROUPS = TQ_BLOCK / G;          // rays in flight per block
     static constexpr int PER_WAVE = 64 / G;
-    static constexpr int LEVELS = G == 4 ? 32 : (G == 2 ? TQ_PAIR_LEVELS : 16);  // stack levels in LDS
+    static constexpr int LEVELS = G == 4 ? 32 : (G == 2 ? TQ_PAIR_LEVELS : TQ_G1_LEVELS);  // stack levels in LDS
     static constexpr int STRIDE = GROUPS + 4;            // entries per level (+4: 32 B skew between levels)
     static constexpr int SPILL = MAX_STACK_ENTRIES + 4 - LEVELS;  // deeper levels in global memory (the builders cap the depth)
 };
@@ -212,7 +224,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
     const int32_t n = n_ptr ? *n_ptr : n_direct;
     if (blockIdx.x == 0 && threadIdx.x == 0 && counter_word >= 0)
         atomicAdd(&counters[counter_word], (unsigned long long)n);
-    static_assert(!QN || G == 2, "compressed nodes: pair kernel only");
+    static_assert(!QN || G <= 2, "compressed nodes: one ray per lane (production) and the pair kernel");
     const char *const node_base = QN ? (const char *)sc.qnodes : (const char *)sc.nodes;
     const char *const prim_base = (const char *)sc.prims;
 
@@ -468,6 +480,27 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                     } else if (advance()) {
                         finish();
                     }
+                } else if constexpr (ANY_HIT && G == 1) {
+                    // the same for one ray per lane: the first hit slot is visited next, the others are pushed
+                    int nhit = 0;
+#pragma unroll
+                    for (int j = 0; j < CPL; j++) nhit += key[j] != TQ_KEY_INVALID;
+                    if (nhit != 0) {
+                        int32_t cand = CHILD_EMPTY;
+                        int pos = 0;
+#pragma unroll
+                        for (int j = 0; j < CPL; j++) {
+                            if (key[j] != TQ_KEY_INVALID) {
+                                if (pos == 0) cand = child[j];
+                                else push_entry(sp + pos - 1, (tq_entry)(uint32_t)child[j]);
+                                pos++;
+                            }
+                        }
+                        sp += nhit - 1;
+                        cur = cand;
+                    } else if (advance()) {
+                        finish();
+                    }
                 } else {
                     // rank of each of my slots among the four keys of the node (keys of the other lanes come by DPP;
                     // a key never compares less than itself, so broadcasting all four is fine)
@@ -486,13 +519,17 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                         const int mine = tq_less(key[0], TQ_KEY_INVALID) + tq_less(key[CPL - 1], TQ_KEY_INVALID);
                         nhit = mine + dpp_i<QP_X1>(mine);
                     } else {
+                        // one ray per lane: six comparisons give all four ranks (valid keys are distinct, so
+                        // [a < b] = 1 - [b < a] wherever it matters: an invalid key is never less than anything)
+                        constexpr int I1 = CPL > 1 ? 1 : 0, I2 = CPL > 2 ? 2 : 0, I3 = CPL - 1;  // (in range for every G)
+                        const int l01 = tq_less(key[0], key[I1]), l02 = tq_less(key[0], key[I2]), l03 = tq_less(key[0], key[I3]);
+                        const int l12 = tq_less(key[I1], key[I2]), l13 = tq_less(key[I1], key[I3]), l23 = tq_less(key[I2], key[I3]);
+                        rank[0] = (1 - l01) + (1 - l02) + (1 - l03);
+                        rank[I1] = l01 + (1 - l12) + (1 - l13);
+                        rank[I2] = l02 + l12 + (1 - l23);
+                        rank[I3] = l03 + l13 + l23;
 #pragma unroll
-                        for (int j = 0; j < CPL; j++) {
-                            rank[j] = 0;
-#pragma unroll
-                            for (int i = 0; i < CPL; i++) rank[j] += tq_less(key[i], key[j]);
-                            nhit += tq_less(key[j], TQ_KEY_INVALID);
-                        }
+                        for (int j = 0; j < CPL; j++) nhit += tq_less(key[j], TQ_KEY_INVALID);
                     }
                     if (nhit != 0) {
                         // the nearest child is visited next and never touches the stack; the others are pushed

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from take_amd import capi, scenes
 
-PW = 32  # ray slots per wave (pair kernel)
+PW = int(os.environ.get("TAKE_DIAG_SLOTS", "64"))  # ray slots per wave: 64 = one ray per lane (production), 32 = pair builds
 tris = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 precision = 1 if (len(sys.argv) > 3 and sys.argv[3] == "f64") else 0

@@ -73,7 +73,7 @@ key = "false, false, tk::PathIo<float>"  # k_trace_group<float, G, ANY_HIT=false
 fetch, nf = counter_total("fetch", "FETCH_SIZE", key)
 write, nw = counter_total("write", "WRITE_SIZE", key)
 if fetch is not None and nf:
-    t = {"kernel": "tk::k_trace_group<float,2,false,false,PathIo<float>,true> (closest hit, pair kernel, compressed nodes)", "launches": nf,
+    t = {"kernel": "tk::k_trace_group<float,1,false,false,PathIo<float>,true> (closest hit, one ray per lane, compressed nodes)", "launches": nf,
          "fetch_bytes_per_launch": fetch * 1024 / nf, "write_bytes_per_launch": (write or 0) * 1024 / max(nw, 1),
          "fetch_correction": FETCH_FACTOR_64B_GATHER,
          "fetch_correction_source": "profiles/r02_fetch_calibration.txt (64-byte random gathers: FETCH_SIZE = 0.999 x bytes)"}
