@@ -124,11 +124,16 @@ TK_HD bool box_test(const NodeChild<R> &c, Vec3<R> o, R idx, R idy, R idz, R tmi
 // BOX_GROW (3 ulp) like the full-width test.
 struct QRay {
     float ax, ay, az, bx, by, bz;
+    // per axis 0 or 16: rotating a slot's (lo | hi << 16) word by this puts the plane the ray meets first into the low
+    // half — the entry and exit distances then come out of the fma directly, without a min / max per axis and box
+    uint32_t rx, ry, rz;
 };
+TK_HD void qray_rotations(QRay &f) { f.rx = f.bx < 0.0f ? 16u : 0u, f.ry = f.by < 0.0f ? 16u : 0u, f.rz = f.bz < 0.0f ? 16u : 0u; }
 TK_HD QRay qray_make(const float *grid_lo, const float *grid_step, Vec3<float> o, float idx, float idy, float idz) {
     QRay f;
     f.ax = (grid_lo[0] - o.x) * idx, f.ay = (grid_lo[1] - o.y) * idy, f.az = (grid_lo[2] - o.z) * idz;
     f.bx = idx * grid_step[0], f.by = idy * grid_step[1], f.bz = idz * grid_step[2];
+    qray_rotations(f);
     return f;
 }
 // f64 rays traverse the same compressed nodes with the same f32 slab test: A and B are formed in double and rounded
@@ -139,6 +144,7 @@ TK_HD QRay qray_make(const float *grid_lo, const float *grid_step, Vec3<double> 
     f.ax = (float)(((double)grid_lo[0] - o.x) * idx), f.ay = (float)(((double)grid_lo[1] - o.y) * idy),
     f.az = (float)(((double)grid_lo[2] - o.z) * idz);
     f.bx = (float)(idx * (double)grid_step[0]), f.by = (float)(idy * (double)grid_step[1]), f.bz = (float)(idz * (double)grid_step[2]);
+    qray_rotations(f);
     return f;
 }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -149,7 +155,9 @@ __device__ __forceinline__ void qplanes(uint32_t w, float b, float a, float &t0,
     const tk_f2 t = __builtin_elementwise_fma(q, (tk_f2){b, b}, (tk_f2){a, a});
     t0 = t.x, t1 = t.y;
 }
+__device__ __forceinline__ uint32_t qrot(uint32_t w, uint32_t r) { return __builtin_amdgcn_alignbit(w, w, r); }
 #else
+inline uint32_t qrot(uint32_t w, uint32_t r) { return r ? ((w >> 16) | (w << 16)) : w; }
 inline void qplanes(uint32_t w, float b, float a, float &t0, float &t1) {
     t0 = __builtin_fmaf((float)(w & 0xffffu), b, a);
     t1 = __builtin_fmaf((float)(w >> 16), b, a);
@@ -157,12 +165,14 @@ inline void qplanes(uint32_t w, float b, float a, float &t0, float &t1) {
 #endif
 // conservative slab test of one compressed child slot
 TK_HD bool qbox_test(const QRay &f, uint32_t qx, uint32_t qy, uint32_t qz, int32_t child, float tmin, float tbest, float &tn) {
-    float t0x, t1x, t0y, t1y, t0z, t1z;
-    qplanes(qx, f.bx, f.ax, t0x, t1x);
-    qplanes(qy, f.by, f.ay, t0y, t1y);
-    qplanes(qz, f.bz, f.az, t0z, t1z);
-    tn = tk_fmax(tk_fmax(tk_fmin(t0x, t1x), tk_fmin(t0y, t1y)), tk_fmax(tk_fmin(t0z, t1z), tmin));
-    const float tf = tk_fmin(tk_fmin(tk_fmax(t0x, t1x), tk_fmax(t0y, t1y)), tk_fmin(tk_fmax(t0z, t1z), tbest));
+    // near / far plane per axis by rotation (QRay): the same two values min / max would pick — the fma is monotone in
+    // the plane coordinate, increasing for a positive slope and decreasing for a negative one
+    float nx, fx, ny, fy, nz, fz;
+    qplanes(qrot(qx, f.rx), f.bx, f.ax, nx, fx);
+    qplanes(qrot(qy, f.ry), f.by, f.ay, ny, fy);
+    qplanes(qrot(qz, f.rz), f.bz, f.az, nz, fz);
+    tn = tk_fmax(tk_fmax(nx, ny), tk_fmax(nz, tmin));
+    const float tf = tk_fmin(tk_fmin(fx, fy), tk_fmin(fz, tbest));
     return (tn * Const<float>::BOX_SHRINK <= tf * Const<float>::BOX_GROW) && (child != CHILD_EMPTY);
 }
 
