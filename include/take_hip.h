@@ -188,7 +188,7 @@ typedef struct TakeSceneDesc {
 typedef struct TakeBuildOpts {
     int32_t precision;     /* TAKE_PRECISION_F32 (production) or _F64 (parity mode) */
     int32_t bvh_threads;   /* host threads for the BVH build; <=0: hardware_concurrency */
-    int32_t max_leaf_size; /* primitives per leaf, 1..4; <=0: default (2 host, 1 device) */
+    int32_t max_leaf_size; /* primitives per leaf, 1..4; <=0: default (1) */
     int32_t builder;       /* TAKE_BUILDER_AUTO (0): host SAH below TAKE_AUTO_DEVICE_BUILD_SHAPES shapes, device
                               LBVH from there on (f32 scenes without instances);
                               TAKE_BUILDER_DEVICE_LBVH: primitive records, Morton-order tree and its compression are

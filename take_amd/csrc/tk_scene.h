@@ -2,7 +2,7 @@
 //
 // Layout rules:
 //  * BVH: 4-wide nodes in breadth-first order (top levels = array prefix).  The render paths of both precisions read
-//    the 64-byte compressed form (QNode4: four 16-byte slots, planes on a 16-bit grid) — a traversal pair loads its
+//    the 64-byte compressed form (QNode4: four 16-byte slots, planes on a 16-bit grid) — a lane loads its ray's
 //    two slots with 2 x dwordx4 per lane, one 64-byte fabric request per node; the full-width form (Node4<R>) is the
 //    builder's output and the fall-back for scenes the grid is too coarse for.
 //  * Primitives are stored in leaf order as pre-transformed 64-byte records (v0, e1, e2 | centre, radius, then the
@@ -52,7 +52,7 @@ static_assert(sizeof(NodeChild<float>) == 32 && sizeof(Node4<float>) == 128, "on
 // builder keeps the full-width nodes (tk_host_scene.h).
 // Why: the traversal is bound by the vector L1, which pays one line look-up per ray and per load instruction, and
 // by VALU issue at the same time (profiles/r01_tcp_counters.txt, r01_ubench_gather.txt).  A slot is
-// 16 B: the pair kernel reads its two slots with 2 x dwordx4 per lane instead of 4, with no cross-lane exchange,
+// 16 B: a lane reads its ray's node with 4 x dwordx4 from one line (the pair build: two slots per lane, no exchange),
 // and because the grid is global the ray is moved into grid space once per ray, not once per node.
 struct QChild {
     uint32_t q[3];  // axis a: lo | hi << 16

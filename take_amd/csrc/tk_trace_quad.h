@@ -1,21 +1,27 @@
-// tk_trace_quad.h — the trace kernel: G lanes cooperate on one ray (G = 2 "pair" is the production setting; G = 4
-// "quad" and G = 1 are kept as instances of the same template for A/B runs and pass the same parity suite).
+// tk_trace_quad.h — the trace kernel.  One template, G lanes per ray: G = 1 (one ray per lane) is the production
+// setting since the nodes are 64 bytes; G = 2 ("pair") and G = 4 ("quad") are kept as instances of the same template
+// for A/B builds (-DTQ_GROUP=2) and pass the same parity suite.
 //
-// Why lanes share a ray (profiles/r01_a_perlane_bvh4_spp4.txt): with one ray per lane every node visit is eight
-// scattered 16-byte requests per lane, 64 different lines per wave instruction, and a wave runs as long as its
-// slowest of 64 rays (VALU lane efficiency ~14 %).  Here
-//   * the lanes of a group split the four child slots of a wide node: one line look-up per ray per load
-//     instruction (the vector L1 charges exactly that, profiles/r01_ubench_gather.txt); with the 64-byte
-//     compressed node (QN) a pair needs 2 x dwordx4 per lane and no cross-lane traffic before the ranking;
-//   * the four entry distances are ranked with DPP exchanges on integer keys (no LDS, no sorting network); the
-//     nearest child stays in a register, the others go far-to-near on a per-group LDS stack (spill area in global
-//     memory behind an out-of-line call);
-//   * a leaf is tested one primitive per lane; hit attributes stay in the lane that found them until the ray ends;
+// History of the choice (profiles/): with full-width 128-byte nodes (round 1) one ray per lane meant eight scattered
+// 16-byte requests per lane and node, and lanes sharing a ray won (quad 143.6, pair 121.5, one ray per lane 128.8 ms
+// per 8.3 M samples).  With the 64-byte compressed node (QN) a lane reads its whole node with 4 x dwordx4 from one
+// line, the per-step bookkeeping (ranking, stack, phase logic: more than half of a step's instructions) is paid once
+// per 64 rays instead of once per 32, leaves hold one primitive, and one ray per lane is ahead: f32 64.7 -> 78.7,
+// f64 44.7 -> 60.0 Msamples/s on the bench scene.
+//   * node step: 24 x v_cvt_f32_u32 (SDWA word select) -> 12 x v_pk_fma_f32 -> entry / exit distances directly (the
+//     slot words are rotated per axis so that the plane met first is the low half: no min / max per axis) -> max3 /
+//     min3; the four entry distances become integer keys (float bits | 3 - slot) and are ranked with six comparisons;
+//     the nearest child stays in a register, the others go far-to-near on a per-ray LDS stack (15 levels of 8-byte
+//     entries, 24-bit-multiply addressing; deeper levels in a global spill area behind an out-of-line call); popped
+//     entries beyond the closest hit are dropped; shadow rays skip ranking and keys;
+//   * a leaf is one primitive (host and device builders), tested by the ray's lane; hit attributes stay there;
 //   * node steps and leaf steps run in separate phases; a wave keeps a pool of 64 queue indices (one atomic per
 //     64 rays) and refills idle ray slots from it, so lanes do not idle behind the longest ray of the wave;
-//   * nothing that loads sits at the end of a ray: that point is on the critical path of the whole wave.
+//   * nothing that loads sits at the end of a ray: that point is on the critical path of the whole wave;
+//   * G >= 2 only: the lanes of a group split the child slots, keys are exchanged by DPP, a leaf's primitives are
+//     dealt to the lanes.
 // Same conservative box tests and the same primitive tests as tk_traverse.h: results are bit-identical to the
-// per-lane traversal and to the oracle; exact ties in t are resolved on (u, v), not on visiting order.
+// per-lane traversal and to the oracle for every G; exact ties in t are resolved on (u, v), not on visiting order.
 #pragma once
 
 #include <hip/hip_runtime.h>
