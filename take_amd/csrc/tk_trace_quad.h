@@ -41,6 +41,9 @@ namespace tk {
 // pair: 6 (measured +4 % over 5; 7 and 8 spill and lose)
 #define TQ_MIN_WAVES (TQ_GROUP == 1 ? 5 : 6)
 #endif
+#ifndef TQ_INST_WAVES
+#define TQ_INST_WAVES (TQ_MIN_WAVES - 1)  // f32 two-level instances: room for the saved world-space ray
+#endif
 #ifndef TQ_F64_WAVES
 #define TQ_F64_WAVES 4  // register cap of the f64 instances (waves per SIMD)
 #endif
@@ -214,7 +217,7 @@ template <int G> __device__ __forceinline__ int group_max_i(int v) {
 // continues at the prototype's root; when the marker is popped the ray gets its world-space form back.  A separate
 // instance of the kernel, so that one-level scenes pay nothing.
 template <class R, int G, bool ANY_HIT, bool COUNT, class Io, bool QN = false, bool INST = false>
-__global__ void __launch_bounds__(TQ_BLOCK, sizeof(R) == 8 ? (INST ? TQ_F64_WAVES - 1 : TQ_F64_WAVES) : (INST ? TQ_MIN_WAVES - 1 : TQ_MIN_WAVES))  // f64, two-level: room for the wider state
+__global__ void __launch_bounds__(TQ_BLOCK, sizeof(R) == 8 ? (INST ? TQ_F64_WAVES - 1 : TQ_F64_WAVES) : (INST ? TQ_INST_WAVES : TQ_MIN_WAVES))  // f64, two-level: room for the wider state
 k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_t n_direct, int32_t *head,
               unsigned long long *counters, int counter_word, StackSpill spill) {
     using GG = GroupGeom<G>;
