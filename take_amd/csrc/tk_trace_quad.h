@@ -600,7 +600,43 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
 #pragma unroll 1
                 for (int k = gl; k < cnt; k += G) {
                     const uint32_t off = (uint32_t)(first + k) * (uint32_t)sizeof(PrimRec<R>);
-                    const PrimRec<R> p = *(const PrimRec<R> *)(prim_base + off);
+                    // the test side of the record (a[9], shape id, meta) as whole 16-byte loads: three (f32) / five
+                    // (f64) line look-ups instead of the five / seven the field-wise loads compile to — the vector L1's
+                    // look-up rate is one of the kernel's limits
+                    struct PrimTest {
+                        R a[9];
+                        int32_t shape_id, meta;
+                    };
+                    static_assert(sizeof(PrimTest) <= (sizeof(R) == 4 ? 48 : 80) && offsetof(PrimRec<R>, meta) == offsetof(PrimTest, meta),
+                                  "the head of PrimRec");
+                    constexpr int NQ = sizeof(R) == 4 ? 3 : 5;
+                    union {
+                        uint4 q[NQ];
+                        PrimTest t;
+                    } rec;
+                    // (inline asm: written as C++ loads the compiler narrows them back to the fields each branch uses)
+                    if constexpr (sizeof(R) == 4) {
+                        asm volatile(
+                            "global_load_dwordx4 %0, %3, %4\n\t"
+                            "global_load_dwordx4 %1, %3, %4 offset:16\n\t"
+                            "global_load_dwordx4 %2, %3, %4 offset:32\n\t"
+                            "s_waitcnt vmcnt(0)"
+                            : "=&v"(rec.q[0]), "=&v"(rec.q[1]), "=&v"(rec.q[2])
+                            : "v"(off), "s"(prim_base)
+                            : "memory");
+                    } else {
+                        asm volatile(
+                            "global_load_dwordx4 %0, %5, %6\n\t"
+                            "global_load_dwordx4 %1, %5, %6 offset:16\n\t"
+                            "global_load_dwordx4 %2, %5, %6 offset:32\n\t"
+                            "global_load_dwordx4 %3, %5, %6 offset:48\n\t"
+                            "global_load_dwordx4 %4, %5, %6 offset:64\n\t"
+                            "s_waitcnt vmcnt(0)"
+                            : "=&v"(rec.q[0]), "=&v"(rec.q[1]), "=&v"(rec.q[2]), "=&v"(rec.q[3]), "=&v"(rec.q[NQ - 1])
+                            : "v"(off), "s"(prim_base)
+                            : "memory");
+                    }
+                    const PrimTest &p = rec.t;
                     R t, u = R(0), v = R(0);
                     // later primitives of this lane see the distance of its earlier hits; the tests accept t == limit,
                     // and an equal distance replaces the candidate only for a larger (u, v) (tree-independent ties)
