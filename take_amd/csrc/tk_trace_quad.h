@@ -6,8 +6,8 @@
 // 16-byte requests per lane and node, and lanes sharing a ray won (quad 143.6, pair 121.5, one ray per lane 128.8 ms
 // per 8.3 M samples).  With the 64-byte compressed node (QN) a lane reads its whole node with 4 x dwordx4 from one
 // line, the per-step bookkeeping (ranking, stack, phase logic: more than half of a step's instructions) is paid once
-// per 64 rays instead of once per 32, leaves hold one primitive, and one ray per lane is ahead: f32 64.7 -> 78.7,
-// f64 44.7 -> 60.0 Msamples/s on the bench scene.
+// per 64 rays instead of once per 32, leaves hold one primitive, and one ray per lane is ahead: f32 65.8 -> 80.0,
+// f64 44.7 -> 61.4 Msamples/s on the bench scene.
 //   * node step: 24 x v_cvt_f32_u32 (SDWA word select) -> 12 x v_pk_fma_f32 -> entry / exit distances directly (the
 //     slot words are rotated per axis so that the plane met first is the low half: no min / max per axis) -> max3 /
 //     min3; the four entry distances become integer keys (float bits | 3 - slot) and are ranked with six comparisons;
