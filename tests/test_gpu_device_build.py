@@ -64,6 +64,30 @@ def test_device_build_leaf_sizes_100k(leaf):
         b.close()
 
 
+@pytest.mark.parametrize("leaf", [2, 4])
+@pytest.mark.parametrize("precision", [D.TAKE_PRECISION_F32, D.TAKE_PRECISION_F64])
+def test_host_build_leaf_sizes_give_the_same_results(leaf, precision):
+    """the host builder's default is one primitive per leaf (one ray per lane tests a leaf's primitives one after the
+    other); larger leaves go through the per-lane primitive loop and must not change a hit or a pixel"""
+    sd = scenes.soup_scene(20_000, 128, 128, spp=1)
+    a = capi.Scene(sd, precision=precision, builder=D.TAKE_BUILDER_HOST_SAH)
+    b = capi.Scene(sd, precision=precision, builder=D.TAKE_BUILDER_HOST_SAH, max_leaf_size=leaf)
+    try:
+        assert b.stats()["n_nodes"] < a.stats()["n_nodes"]
+        r = random_rays(50_000, 12, tmin=1e-4 if precision == D.TAKE_PRECISION_F32 else 1e-7)
+        if precision == D.TAKE_PRECISION_F32:
+            r = r.astype(np.float32).astype(np.float64)
+        rays = rays_to_abi(r, precision)
+        ha, hb = a.trace_closest(rays), b.trace_closest(rays)
+        for f in ("shape_id", "t", "u", "v"):
+            assert np.array_equal(ha[f], hb[f]), f
+        assert np.array_equal(a.trace_any(rays), b.trace_any(rays))
+        assert np.array_equal(a.render(spp=2, max_depth=20, seed=1), b.render(spp=2, max_depth=20, seed=1))
+    finally:
+        a.close()
+        b.close()
+
+
 def test_device_build_1m_triangles_same_results_and_build_time():
     sd = scenes.soup_scene(1_000_000, 1920, 1080, spp=1)
     t0 = time.time()
