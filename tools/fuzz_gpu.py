@@ -1,5 +1,5 @@
 """Exploratory GPU fuzz (more seeds than the committed tests/test_fuzz_scenes.py): random scenes, hit tables vs exhaustive
-search, f64 renders of all four integrators vs the oracle, f32 host-built vs device-built tree.  usage: fuzz_gpu.py"""
+search, f64 renders of all four integrators vs the oracle, f32 host-built vs device-built tree.  usage: fuzz_gpu.py [first_seed last_seed]"""
 import sys
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,8 @@ from helpers import rays_to_abi, rmse
 from take_amd import capi
 from take_amd import cdefs as D
 bad=0
-for seed in range(13, 61):
+first, last = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (13, 60)
+for seed in range(first, last + 1):
     sd, scale = random_scene(seed, res=20)
     for precision in (1, 0):
         f64 = precision==1
