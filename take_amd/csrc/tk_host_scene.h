@@ -275,6 +275,24 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
         o.p0 = R(m.param[0]);
         o.p1 = R(m.param[1]);
         for (int k = 0; k < TAKE_MATERIAL_PARAMS; k++) o.p[k] = R(m.param[k]);
+        if (o.tag >= TAKE_MAT_BURLEY_METAL && o.tag <= TAKE_MAT_BURLEY_BSDF) {
+            // the Burley lobes take square roots and logarithms of their parameters: a value outside the model's range
+            // (every parameter in [0, 1], an index of refraction > 0) would render NaN pixels — refuse it here
+            auto unit = [&](int k) { return m.param[k] >= 0.0 && m.param[k] <= 1.0; };  // (false for NaN)
+            bool ok = true;
+            int eta_at = -1;
+            switch (o.tag) {
+                case TAKE_MAT_BURLEY_METAL: ok = unit(0) && unit(1); break;
+                case TAKE_MAT_BURLEY_GLASS: ok = unit(0) && unit(1), eta_at = 2; break;
+                case TAKE_MAT_BURLEY_CLEARCOAT:
+                case TAKE_MAT_BURLEY_SHEEN: ok = unit(0); break;
+                default:
+                    for (int k = 0; k < 11; k++) ok = ok && unit(k);
+                    eta_at = 11;
+            }
+            if (eta_at >= 0) ok = ok && m.param[eta_at] > 0.0 && std::isfinite(m.param[eta_at]);
+            if (!ok) return "material " + std::to_string(i) + ": Burley parameter outside [0, 1] (or eta <= 0)";
+        }
         tag_used[o.tag] = true;
     }
     hs.n_material_tags = 0;

@@ -310,3 +310,26 @@ def test_other_integrators_take_the_lobes_too(integrator):
     osc.close()
     got, _ = hostsim_render(sd, 1, 2, 6, seed=1, integrator=integrator)
     assert np.array_equal(got, want)
+
+
+def test_out_of_range_parameters_are_refused():
+    """sqrt(1 - 0.9 anisotropic), log(alpha_g^2), 1 / eta: a parameter outside the model's range would render NaN —
+    scene preparation (the code the C ABI runs before anything reaches the GPU) rejects it with a message"""
+    from helpers import hostsim_render
+    from take_amd import scenes
+    from take_amd.scene import SceneData
+    from take_amd import cdefs as D
+
+    def scene(tag, params):
+        sd = SceneData(width=8, height=8, lookfrom=(0.0, 0.0, 3.0), lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), vfov=40.0,
+                       background=(0.5, 0.5, 0.5), spp=1, max_depth=2)
+        sd.add_sphere((0.0, 0.0, 0.0), 0.5, sd.add_material(tag, (0.5, 0.5, 0.5), params))
+        return sd
+
+    hostsim_render(scene(D.MAT_BURLEY_METAL, (0.3, 1.0)), 1, 1, 2)  # in range: fine
+    hostsim_render(scene(D.MAT_DISNEY_METAL, (0.3, 7.0)), 1, 1, 2)  # the reference's stub ignores its parameters
+    for tag, params in ((D.MAT_BURLEY_METAL, (0.3, 1.5)), (D.MAT_BURLEY_GLASS, (0.3, 0.0, 0.0)),
+                        (D.MAT_BURLEY_GLASS, (float("nan"), 0.0, 1.5)), (D.MAT_BURLEY_CLEARCOAT, (-0.1,)),
+                        (D.MAT_BURLEY_BSDF, scenes.principled(metallic=1.2)), (D.MAT_BURLEY_BSDF, scenes.principled(eta=-1.0))):
+        with pytest.raises(RuntimeError, match="Burley parameter"):
+            hostsim_render(scene(tag, params), 1, 1, 2)
