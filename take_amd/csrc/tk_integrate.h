@@ -87,8 +87,8 @@ constexpr int TAG_MISS = TAKE_MAT_COUNT;   // the segment of the sorted queue ho
 // ray's hit, k >= 1 finishes loop iteration k-1; iteration k is started when k <= max_depth.
 // TAG: compile-time material tag of the vertex being shaded (see tk_shade.h); a TAG instance may still meet a
 // miss when the queue is not sorted (single-tag scenes).  Returns REQ_* bits: which rays to trace next.
-template <class R, int TAG = TAG_ANY>
-TK_HD uint32_t shade_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, const PathState<R> &st, int64_t slot,
+template <class R, int TAG = TAG_ANY, class ST = PathState<R>>
+TK_HD uint32_t shade_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, const ST &st, int64_t slot,
                           int k) {
     const int32_t hit_prim = st.I_(S_HIT, slot);
     const Vec3<R> ro{st.R_(S_OX, slot), st.R_(S_OY, slot), st.R_(S_OZ, slot)};

@@ -56,6 +56,19 @@ k_generate(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, int32_t *queu
 // (single-tag scenes) the one instance of the scene's tag walks the whole queue.
 // ALT: the reference's other integrators (shade_path_alt, tk_integrate.h; rp.integrator 1..3) — separate instances, so
 // that the default integrator's register allocation is untouched.
+#ifndef TK_SHADE_RECORD
+#define TK_SHADE_RECORD 1  // f32 shade kernels of the default integrator work on a register copy of the path record (0: in memory)
+#endif
+// one path's record held in registers: the accessors of PathState on a local copy
+template <class R> struct RecordView {
+    union {
+        mutable uint4 q[PATH_REC / 4];
+        mutable R w[PATH_REC];
+    };
+    __device__ __forceinline__ RecordView() {}
+    __device__ __forceinline__ R &R_(int c, int64_t) const { return w[c]; }
+    __device__ __forceinline__ int32_t &I_(int c, int64_t) const { return *reinterpret_cast<int32_t *>(&w[c]); }
+};
 template <class R, int TAG, bool ALT = false>
 __global__ void __launch_bounds__(BLOCK)
 k_shade(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, const int32_t *__restrict__ queue,
@@ -75,6 +88,34 @@ k_shade(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, const int32_t *_
     int32_t slot = 0;
     if (i < n) {
         slot = queue[begin + i];
+#if TK_SHADE_RECORD
+        if constexpr (sizeof(R) == 4 && !ALT) {
+            // the whole 128-byte record in registers: eight 16-byte loads up front and eight 16-byte stores at the end
+            // instead of field-wise accesses spread over the function, each a request of its own per lane and a
+            // dependency of its own (measured: shade kernel -12 %; 98 instead of 68 VGPRs, 5 waves instead of 7).
+            // Inline asm: written as C++ loads the compiler narrows them back to the fields each branch reads.
+            RecordView<R> rv;
+            const char *rec = (const char *)(st.r + (int64_t)slot * PATH_REC);
+            asm volatile(
+                "global_load_dwordx4 %0, %8, off\n\t"
+                "global_load_dwordx4 %1, %8, off offset:16\n\t"
+                "global_load_dwordx4 %2, %8, off offset:32\n\t"
+                "global_load_dwordx4 %3, %8, off offset:48\n\t"
+                "global_load_dwordx4 %4, %8, off offset:64\n\t"
+                "global_load_dwordx4 %5, %8, off offset:80\n\t"
+                "global_load_dwordx4 %6, %8, off offset:96\n\t"
+                "global_load_dwordx4 %7, %8, off offset:112\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(rv.q[0]), "=&v"(rv.q[1]), "=&v"(rv.q[2]), "=&v"(rv.q[3]), "=&v"(rv.q[4]), "=&v"(rv.q[5]), "=&v"(rv.q[6]),
+                  "=&v"(rv.q[7])
+                : "v"(rec)
+                : "memory");
+            req = shade_path<R, TAG, RecordView<R>>(sc, rp, rv, (int64_t)slot, k);
+            uint4 *out = (uint4 *)(st.r + (int64_t)slot * PATH_REC);
+#pragma unroll
+            for (int c = 0; c < PATH_REC / 4; c++) out[c] = rv.q[c];
+        } else
+#endif
         req = ALT ? shade_path_alt<R, TAG>(sc, rp, st, (int64_t)slot, k) : shade_path<R, TAG>(sc, rp, st, (int64_t)slot, k);
     }
     // Block-aggregated append to the two output queues: ballot + mbcnt inside each wave, wave counts combined in
