@@ -272,8 +272,8 @@ template <class R, class G> TK_HD int sample_light_by_power(const DeviceScene<R>
     return off < 0 ? 0 : (off > size - 1 ? size - 1 : off);
 }
 
-template <class R, int TAG = TAG_ANY>
-TK_HD uint32_t shade_path_alt(const DeviceScene<R> &sc, const RenderParams<R> &rp, const PathState<R> &st, int64_t slot,
+template <class R, int TAG = TAG_ANY, class ST = PathState<R>>
+TK_HD uint32_t shade_path_alt(const DeviceScene<R> &sc, const RenderParams<R> &rp, const ST &st, int64_t slot,
                               int k) {
     const bool raw = rp.integrator == 1, power = rp.integrator == 3;
     const int32_t hit_prim = st.I_(S_HIT, slot);

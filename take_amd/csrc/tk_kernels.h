@@ -57,7 +57,7 @@ k_generate(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, int32_t *queu
 // ALT: the reference's other integrators (shade_path_alt, tk_integrate.h; rp.integrator 1..3) — separate instances, so
 // that the default integrator's register allocation is untouched.
 #ifndef TK_SHADE_RECORD
-#define TK_SHADE_RECORD 1  // f32 shade kernels of the default integrator work on a register copy of the path record (0: in memory)
+#define TK_SHADE_RECORD 1  // the f32 shade kernels work on a register copy of the path record (0: in memory)
 #endif
 // one path's record held in registers: the accessors of PathState on a local copy
 template <class R> struct RecordView {
@@ -89,7 +89,7 @@ k_shade(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, const int32_t *_
     if (i < n) {
         slot = queue[begin + i];
 #if TK_SHADE_RECORD
-        if constexpr (sizeof(R) == 4 && !ALT) {
+        if constexpr (sizeof(R) == 4) {
             // the whole 128-byte record in registers: eight 16-byte loads up front and eight 16-byte stores at the end
             // instead of field-wise accesses spread over the function, each a request of its own per lane and a
             // dependency of its own (measured: shade kernel -12 %; 98 instead of 68 VGPRs, 5 waves instead of 7).
@@ -110,7 +110,8 @@ k_shade(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, const int32_t *_
                   "=&v"(rv.q[7])
                 : "v"(rec)
                 : "memory");
-            req = shade_path<R, TAG, RecordView<R>>(sc, rp, rv, (int64_t)slot, k);
+            req = ALT ? shade_path_alt<R, TAG, RecordView<R>>(sc, rp, rv, (int64_t)slot, k)
+                      : shade_path<R, TAG, RecordView<R>>(sc, rp, rv, (int64_t)slot, k);
             uint4 *out = (uint4 *)(st.r + (int64_t)slot * PATH_REC);
 #pragma unroll
             for (int c = 0; c < PATH_REC / 4; c++) out[c] = rv.q[c];
