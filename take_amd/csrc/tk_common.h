@@ -127,6 +127,59 @@ template <class R> TK_HD Vec3<R> to_world(Vec3<R> n, Vec3<R> v) {
     return x * v.x + y * v.y + n * v.z;
 }
 
+// ---- whole-record loads (device).  A record read as plain C++ is loaded field by field where each branch needs it: more
+// requests per lane, and dependent ones.  load_record issues sizeof(T) / 16 16-byte loads back to back and waits once —
+// inline asm, because the compiler narrows C++ loads back to the fields that are used.  T: 16-byte multiple, 4-byte
+// aligned; the shade kernels use it for the primitive record of a hit.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> __device__ __forceinline__ void load_record(const T *src, T &dst) {
+    constexpr int N = (int)(sizeof(T) / 16);
+    static_assert(sizeof(T) % 16 == 0 && (N == 4 || N == 6 || N == 7), "record sizes in use: 64, 96, 112 bytes");
+    uint4 q0, q1, q2, q3, q4, q5, q6;
+    const char *p = (const char *)src;
+    if constexpr (N == 4) {
+        asm volatile(
+            "global_load_dwordx4 %0, %4, off\n\t"
+            "global_load_dwordx4 %1, %4, off offset:16\n\t"
+            "global_load_dwordx4 %2, %4, off offset:32\n\t"
+            "global_load_dwordx4 %3, %4, off offset:48\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+            : "v"(p)
+            : "memory");
+    } else if constexpr (N == 6) {
+        asm volatile(
+            "global_load_dwordx4 %0, %6, off\n\t"
+            "global_load_dwordx4 %1, %6, off offset:16\n\t"
+            "global_load_dwordx4 %2, %6, off offset:32\n\t"
+            "global_load_dwordx4 %3, %6, off offset:48\n\t"
+            "global_load_dwordx4 %4, %6, off offset:64\n\t"
+            "global_load_dwordx4 %5, %6, off offset:80\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5)
+            : "v"(p)
+            : "memory");
+    } else {
+        asm volatile(
+            "global_load_dwordx4 %0, %7, off\n\t"
+            "global_load_dwordx4 %1, %7, off offset:16\n\t"
+            "global_load_dwordx4 %2, %7, off offset:32\n\t"
+            "global_load_dwordx4 %3, %7, off offset:48\n\t"
+            "global_load_dwordx4 %4, %7, off offset:64\n\t"
+            "global_load_dwordx4 %5, %7, off offset:80\n\t"
+            "global_load_dwordx4 %6, %7, off offset:96\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6)
+            : "v"(p)
+            : "memory");
+    }
+    uint4 *d = (uint4 *)&dst;
+    d[0] = q0, d[1] = q1, d[2] = q2, d[3] = q3;
+    if constexpr (N >= 6) d[4] = q4, d[5] = q5;
+    if constexpr (N >= 7) d[6] = q6;
+}
+#endif
+
 // ---- counter-based random stream (specification: DESIGN.md §RNG; pinned by tests against
 // oracle_counter_words).  One 64-bit word per random_real(); f32 keeps the top 24 bits, f64 the top 53.
 struct Rng {

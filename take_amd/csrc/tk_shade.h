@@ -33,43 +33,11 @@ template <class R>
 TK_HD void make_isect(const DeviceScene<R> &sc, Vec3<R> ro, Vec3<R> rd, int32_t prim, R t, R u, R v, Isect<R> &out,
                       int32_t inst = -1) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // the whole record with 16-byte loads (four in f32, six in f64), all in flight at once: written as plain C++ the
-    // compiler reads it field by field where each branch needs it — more requests per lane, and dependent ones
-    // (measured on the f32 shade kernel: -8 %)
-    constexpr int NQ = (int)(sizeof(PrimRec<R>) / 16);
-    static_assert(NQ == 4 || NQ == 6, "PrimRec: 64 bytes (f32) or 96 bytes (f64)");
-    union {
-        uint4 q[NQ];
-        PrimRec<R> rec;
-    } whole;
-    {
-        const char *src = (const char *)(sc.prims + prim);
-        if constexpr (NQ == 4) {
-            asm volatile(
-                "global_load_dwordx4 %0, %4, off\n\t"
-                "global_load_dwordx4 %1, %4, off offset:16\n\t"
-                "global_load_dwordx4 %2, %4, off offset:32\n\t"
-                "global_load_dwordx4 %3, %4, off offset:48\n\t"
-                "s_waitcnt vmcnt(0)"
-                : "=&v"(whole.q[0]), "=&v"(whole.q[1]), "=&v"(whole.q[2]), "=&v"(whole.q[3])
-                : "v"(src)
-                : "memory");
-        } else {
-            asm volatile(
-                "global_load_dwordx4 %0, %6, off\n\t"
-                "global_load_dwordx4 %1, %6, off offset:16\n\t"
-                "global_load_dwordx4 %2, %6, off offset:32\n\t"
-                "global_load_dwordx4 %3, %6, off offset:48\n\t"
-                "global_load_dwordx4 %4, %6, off offset:64\n\t"
-                "global_load_dwordx4 %5, %6, off offset:80\n\t"
-                "s_waitcnt vmcnt(0)"
-                : "=&v"(whole.q[0]), "=&v"(whole.q[1]), "=&v"(whole.q[2]), "=&v"(whole.q[3]), "=&v"(whole.q[NQ - 2]),
-                  "=&v"(whole.q[NQ - 1])
-                : "v"(src)
-                : "memory");
-        }
-    }
-    const PrimRec<R> &p = whole.rec;
+    // the whole record with 16-byte loads (four in f32, six in f64), all in flight at once (tk_common.h: load_record;
+    // measured on the f32 shade kernel: -8 %)
+    PrimRec<R> whole;
+    load_record(sc.prims + prim, whole);
+    const PrimRec<R> &p = whole;
 #else
     const PrimRec<R> &p = sc.prims[prim];
 #endif
