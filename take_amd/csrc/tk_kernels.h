@@ -57,12 +57,12 @@ k_generate(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, int32_t *queu
 // ALT: the reference's other integrators (shade_path_alt, tk_integrate.h; rp.integrator 1..3) — separate instances, so
 // that the default integrator's register allocation is untouched.
 #ifndef TK_SHADE_RECORD
-#define TK_SHADE_RECORD 1  // the f32 shade kernels work on a register copy of the path record (0: in memory)
+#define TK_SHADE_RECORD 1  // the shade kernels work on a register copy of the path record (0: in memory)
 #endif
 // one path's record held in registers: the accessors of PathState on a local copy
 template <class R> struct RecordView {
     union {
-        mutable uint4 q[PATH_REC / 4];
+        mutable uint4 q[PATH_REC * sizeof(R) / 16];
         mutable R w[PATH_REC];
     };
     __device__ __forceinline__ RecordView() {}
@@ -115,6 +115,40 @@ k_shade(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, const int32_t *_
             uint4 *out = (uint4 *)(st.r + (int64_t)slot * PATH_REC);
 #pragma unroll
             for (int c = 0; c < PATH_REC / 4; c++) out[c] = rv.q[c];
+        } else
+#endif
+#if TK_SHADE_RECORD
+        if constexpr (sizeof(R) == 8) {  // the 256-byte f64 record: 64 registers (measured: shade kernel -11 %)
+            RecordView<R> rv;
+            const char *rec = (const char *)(st.r + (int64_t)slot * PATH_REC);
+            asm volatile(
+                "global_load_dwordx4 %0, %16, off\n\t"
+                "global_load_dwordx4 %1, %16, off offset:16\n\t"
+                "global_load_dwordx4 %2, %16, off offset:32\n\t"
+                "global_load_dwordx4 %3, %16, off offset:48\n\t"
+                "global_load_dwordx4 %4, %16, off offset:64\n\t"
+                "global_load_dwordx4 %5, %16, off offset:80\n\t"
+                "global_load_dwordx4 %6, %16, off offset:96\n\t"
+                "global_load_dwordx4 %7, %16, off offset:112\n\t"
+                "global_load_dwordx4 %8, %16, off offset:128\n\t"
+                "global_load_dwordx4 %9, %16, off offset:144\n\t"
+                "global_load_dwordx4 %10, %16, off offset:160\n\t"
+                "global_load_dwordx4 %11, %16, off offset:176\n\t"
+                "global_load_dwordx4 %12, %16, off offset:192\n\t"
+                "global_load_dwordx4 %13, %16, off offset:208\n\t"
+                "global_load_dwordx4 %14, %16, off offset:224\n\t"
+                "global_load_dwordx4 %15, %16, off offset:240\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(rv.q[0]), "=&v"(rv.q[1]), "=&v"(rv.q[2]), "=&v"(rv.q[3]), "=&v"(rv.q[4]), "=&v"(rv.q[5]), "=&v"(rv.q[6]),
+                  "=&v"(rv.q[7]), "=&v"(rv.q[8]), "=&v"(rv.q[9]), "=&v"(rv.q[10]), "=&v"(rv.q[11]), "=&v"(rv.q[12]),
+                  "=&v"(rv.q[13]), "=&v"(rv.q[14]), "=&v"(rv.q[15])
+                : "v"(rec)
+                : "memory");
+            req = ALT ? shade_path_alt<R, TAG, RecordView<R>>(sc, rp, rv, (int64_t)slot, k)
+                      : shade_path<R, TAG, RecordView<R>>(sc, rp, rv, (int64_t)slot, k);
+            uint4 *out = (uint4 *)(st.r + (int64_t)slot * PATH_REC);
+#pragma unroll
+            for (int c = 0; c < 16; c++) out[c] = rv.q[c];
         } else
 #endif
         req = ALT ? shade_path_alt<R, TAG>(sc, rp, st, (int64_t)slot, k) : shade_path<R, TAG>(sc, rp, st, (int64_t)slot, k);
