@@ -7,7 +7,7 @@
 // per 8.3 M samples).  With the 64-byte compressed node (QN) a lane reads its whole node with 4 x dwordx4 from one
 // line, the per-step bookkeeping (ranking, stack, phase logic: more than half of a step's instructions) is paid once
 // per 64 rays instead of once per 32, leaves hold one primitive, and one ray per lane is ahead: f32 65.8 -> 80.0,
-// f64 44.7 -> 61.4 Msamples/s on the bench scene (82.3 / 61.7 with the whole-record loads of the shade kernels).
+// f64 44.7 -> 61.4 Msamples/s on the bench scene (83.3 / 63.5 with the whole-record loads of the shade kernels).
 //   * node step: 24 x v_cvt_f32_u32 (SDWA word select) -> 12 x v_pk_fma_f32 -> entry / exit distances directly (the
 //     slot words are rotated per axis so that the plane met first is the low half: no min / max per axis) -> max3 /
 //     min3; the four entry distances become integer keys (float bits | 3 - slot) and are ranked with six comparisons;
