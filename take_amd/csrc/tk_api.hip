@@ -104,6 +104,7 @@ template <class R> struct SceneT {
     HostScene<R> host;  // kept: cheap relative to HBM copies, used for stats
     DevBuf<Node4<R>> nodes;
     DevBuf<QNode4> qnodes;
+    DevBuf<QNode8> qnodes8;
     DevBuf<PrimRec<R>> prims;
     DevBuf<ShapeInfo> shapes;
     DevBuf<MeshInfo> meshes;
@@ -134,11 +135,11 @@ template <class R> struct SceneT {
     int64_t spill_stride = 0;  // ray groups in the persistent trace grid
 
     size_t scene_bytes() const {
-        return nodes.bytes() + qnodes.bytes() + prims.bytes() + shapes.bytes() + meshes.bytes() + face_idx.bytes() + normals.bytes() +
+        return nodes.bytes() + qnodes.bytes() + qnodes8.bytes() + prims.bytes() + shapes.bytes() + meshes.bytes() + face_idx.bytes() + normals.bytes() +
                uvs.bytes() + texels.bytes() + materials.bytes() + images.bytes() + lights.bytes() + inst_trace.bytes() + inst_shade.bytes();
     }
     void release() {
-        nodes.release(), qnodes.release(), prims.release(), shapes.release(), meshes.release(), face_idx.release();
+        nodes.release(), qnodes.release(), qnodes8.release(), prims.release(), shapes.release(), meshes.release(), face_idx.release();
         normals.release(), uvs.release(), texels.release(), materials.release(), images.release(), lights.release();
         env_marginal.release(), env_conditional.release(), env_guide_m.release(), env_guide_c.release();
         light_pmf.release(), light_cdf.release(), inst_trace.release(), inst_shade.release();
@@ -265,7 +266,7 @@ int build_bvh_device(SceneT<float> &sc, int max_leaf, bool compressed_ok, bool c
     if (compressed_ok) {
         double lo[3], hi[3];
         for (int a = 0; a < 3; a++) lo[a] = ord2f(ord_h[a]), hi[a] = ord2f(ord_h[3 + a]);
-        const Grid g = make_grid(lo, hi);
+        const QGrid g = make_qgrid(lo, hi);
         HIP_TRY(sc.qnodes.alloc((size_t)n_nodes));
         HIP_TRY(acc.alloc(2));
         HIP_TRY(hipMemsetAsync(acc.p, 0, acc.bytes(), stream));
@@ -400,15 +401,16 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
         clock.lap("primitive records -> HBM");
     }
     if (!on_device) {
-        use_q = sc.group <= 2 && !h.qnodes.empty();  // compressed nodes (not in the quad kernel)
-        if (use_q) HIP_TRY(sc.qnodes.upload(h.qnodes));
+        use_q = sc.group <= 2 && (!h.qnodes.empty() || !h.qnodes8.empty());  // compressed nodes (not in the quad kernel)
+        if (!h.qnodes8.empty()) HIP_TRY(sc.qnodes8.upload(h.qnodes8));
+        else if (use_q) HIP_TRY(sc.qnodes.upload(h.qnodes));
         else HIP_TRY(sc.nodes.upload(h.nodes));
     }
     sc.built_on_device = on_device;
     clock.lap(on_device ? "device LBVH build" : "nodes -> HBM");
     // the trace kernels address nodes and primitive records with 32-bit byte offsets (full-rate integer math)
     {
-        const uint64_t node_bytes = (uint64_t)h.stats.n_nodes * (use_q ? sizeof(QNode4) : sizeof(Node4<R>));
+        const uint64_t node_bytes = (uint64_t)h.stats.n_nodes * (sc.qnodes8.p ? sizeof(QNode8) : (use_q ? sizeof(QNode4) : sizeof(Node4<R>)));
         const uint64_t prim_bytes = (uint64_t)sc.prims.n * sizeof(PrimRec<R>);
         if (node_bytes >= (1ull << 32) || prim_bytes >= (1ull << 32))
             return fail(TAKE_E_INVALID, "scene too large for the 32-bit record offsets of the trace kernels (" +
@@ -436,6 +438,7 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     d.n_nodes = (int32_t)h.stats.n_nodes;
     d.nodes = sc.nodes.p;
     d.qnodes = use_q ? sc.qnodes.p : nullptr;
+    d.qnodes8 = sc.qnodes8.p;
     d.prims = sc.prims.p;
     d.shapes = nullptr;
     d.meshes = sc.meshes.p;
@@ -460,12 +463,20 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     HIP_TRY(hipMemset(sc.counters.p, 0, sc.counters.bytes()));
     // persistent trace grid: resident blocks of the heaviest trace kernel x CUs
     int per_cu = 0;
-    const int groups_per_block = GroupGeom<TQ_GROUP>::GROUPS, spill_levels = GroupGeom<TQ_GROUP>::SPILL;
-    if (use_q) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, TQ_GROUP, false, false, PathIo<R>, true>, TQ_BLOCK, 0));
-    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, TQ_GROUP, false, false, PathIo<R>>, TQ_BLOCK, 0));
-    if (sc.inst_trace.n) {  // two-level scenes run the INST instances: size the persistent grid for them
-        if (use_q) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, TQ_GROUP, false, false, PathIo<R>, true, true>, TQ_BLOCK, 0));
-        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, TQ_GROUP, false, false, PathIo<R>, false, true>, TQ_BLOCK, 0));
+    const bool w8 = sc.qnodes8.p != nullptr;
+    const int groups_per_block = GroupGeom<TQ_GROUP>::GROUPS;
+    const int spill_levels = w8 ? GroupGeom<TQ_GROUP == 1 ? 1 : TQ_GROUP, TQ_GROUP == 1 ? 8 : 4>::SPILL : GroupGeom<TQ_GROUP>::SPILL;
+    if constexpr (TQ_GROUP == 1) {
+        if (w8 && sc.inst_trace.n) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 1, false, false, PathIo<R>, true, true, 8>, TQ_BLOCK, 0));
+        else if (w8) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, 1, false, false, PathIo<R>, true, false, 8>, TQ_BLOCK, 0));
+    }
+    if (!w8) {
+        if (use_q) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, TQ_GROUP, false, false, PathIo<R>, true>, TQ_BLOCK, 0));
+        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, TQ_GROUP, false, false, PathIo<R>>, TQ_BLOCK, 0));
+        if (sc.inst_trace.n) {  // two-level scenes run the INST instances: size the persistent grid for them
+            if (use_q) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, TQ_GROUP, false, false, PathIo<R>, true, true>, TQ_BLOCK, 0));
+            else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_group<R, TQ_GROUP, false, false, PathIo<R>, false, true>, TQ_BLOCK, 0));
+        }
     }
     per_cu = std::max(1, std::min(per_cu, 8));
     if (const char *e = std::getenv("TAKE_HIP_TRACE_BLOCKS")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));  // experiment: leave room for a concurrent kernel
@@ -475,7 +486,7 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     clock.lap("shading tables -> HBM, grid");
     // everything the kernels read is in HBM now; the host keeps the small tables (camera, material tags, tree
     // statistics) and drops the copies of the large arrays (1.1 GB at 10M triangles)
-    h.nodes = {}, h.qnodes = {}, h.prims = {}, h.shapes = {}, h.face_idx = {}, h.normals = {}, h.uvs = {}, h.texels = {};
+    h.nodes = {}, h.qnodes = {}, h.qnodes8 = {}, h.nodes8 = {}, h.prims = {}, h.shapes = {}, h.face_idx = {}, h.normals = {}, h.uvs = {}, h.texels = {};
     h.inst_trace = {}, h.inst_shade = {};
     return TAKE_OK;
 }
@@ -559,22 +570,29 @@ template <class R, class Io>
 void launch_trace(int group, bool any, bool count, dim3 grid, hipStream_t stream, const DeviceScene<R> &dev, const Io &io,
                   const int32_t *n_ptr, int32_t n_direct, int32_t *head, unsigned long long *counters, int counter_word,
                   StackSpill spill) {
-#define TK_LAUNCH(A, C, Q, I)                                                                                              \
-    hipLaunchKernelGGL((k_trace_group<R, TQ_GROUP, A, C, Io, Q, I>), grid, dim3(TQ_BLOCK), 0, stream, dev, io, n_ptr, n_direct, head, \
+#define TK_LAUNCH(A, C, Q, I, W)                                                                                              \
+    hipLaunchKernelGGL((k_trace_group<R, TQ_GROUP, A, C, Io, Q, I, W>), grid, dim3(TQ_BLOCK), 0, stream, dev, io, n_ptr, n_direct, head, \
                        counters, counter_word, spill)
-#define TK_LAUNCH_AC(Q, I)                          \
+#define TK_LAUNCH_AC(Q, I, W)                          \
     do {                                            \
-        if (any && count) TK_LAUNCH(true, true, Q, I);       \
-        else if (any) TK_LAUNCH(true, false, Q, I);          \
-        else if (count) TK_LAUNCH(false, true, Q, I);        \
-        else TK_LAUNCH(false, false, Q, I);                  \
+        if (any && count) TK_LAUNCH(true, true, Q, I, W);       \
+        else if (any) TK_LAUNCH(true, false, Q, I, W);          \
+        else if (count) TK_LAUNCH(false, true, Q, I, W);        \
+        else TK_LAUNCH(false, false, Q, I, W);                  \
     } while (0)
     (void)group;  // one instantiated group size (TQ_GROUP)
     const bool q = dev.qnodes != nullptr, two_level = dev.inst_trace != nullptr;
-    if (q && two_level) TK_LAUNCH_AC(true, true);
-    else if (q) TK_LAUNCH_AC(true, false);
-    else if (two_level) TK_LAUNCH_AC(false, true);
-    else TK_LAUNCH_AC(false, false);
+    if constexpr (TQ_GROUP == 1) {
+        if (dev.qnodes8 != nullptr) {  // the 8-wide tree
+            if (two_level) TK_LAUNCH_AC(true, true, 8);
+            else TK_LAUNCH_AC(true, false, 8);
+            return;
+        }
+    }
+    if (q && two_level) TK_LAUNCH_AC(true, true, 4);
+    else if (q) TK_LAUNCH_AC(true, false, 4);
+    else if (two_level) TK_LAUNCH_AC(false, true, 4);
+    else TK_LAUNCH_AC(false, false, 4);
 #undef TK_LAUNCH_AC
 #undef TK_LAUNCH
 }
@@ -650,7 +668,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     const int n_rows = rows_of(H, first, stride, nullptr);
     const int64_t npix = (int64_t)n_rows * W;
     ts->counters = TakeCounters{};
-    ts->counters.node_bytes = sc.dev.qnodes ? sizeof(QNode4) : sizeof(Node4<R>);
+    ts->counters.node_bytes = sc.dev.qnodes8 ? sizeof(QNode8) : (sc.dev.qnodes ? sizeof(QNode4) : sizeof(Node4<R>));
     ts->counters.prim_bytes = PRIM_TEST_BYTES * (int)(sizeof(R) / 4);
     if (npix == 0) return TAKE_OK;
     if (npix >= ((int64_t)1 << 30)) return fail(TAKE_E_INVALID, "image too large");
@@ -874,7 +892,7 @@ int trace_impl(TakeScene *ts, const void *d_rays, int64_t n, void *d_hits, int32
     unsigned long long c[C_NUM_WORDS];
     HIP_TRY(hipMemcpy(c, sc.counters.p, sizeof c, hipMemcpyDeviceToHost));
     ts->counters = TakeCounters{};
-    ts->counters.node_bytes = sc.dev.qnodes ? sizeof(QNode4) : sizeof(Node4<R>);
+    ts->counters.node_bytes = sc.dev.qnodes8 ? sizeof(QNode8) : (sc.dev.qnodes ? sizeof(QNode4) : sizeof(Node4<R>));
     ts->counters.prim_bytes = PRIM_TEST_BYTES * (int)(sizeof(R) / 4);
     (any ? ts->counters.rays_shadow : ts->counters.rays_closest) = (uint64_t)n;
     ts->counters.node_visits = c[C_NODE_VISITS];
@@ -1175,7 +1193,7 @@ template <class T> int peer_copy(DevBuf<T> &dst, int dst_dev, const DevBuf<T> &s
 template <class R> int replicate_t(const SceneT<R> &a, int a_dev, SceneT<R> &b, int b_dev) {
     int rc = TAKE_OK;
 #define TK_COPY(member) if (!rc) rc = peer_copy(b.member, b_dev, a.member, a_dev)
-    TK_COPY(nodes); TK_COPY(qnodes); TK_COPY(prims); TK_COPY(meshes); TK_COPY(face_idx); TK_COPY(normals); TK_COPY(uvs);
+    TK_COPY(nodes); TK_COPY(qnodes); TK_COPY(qnodes8); TK_COPY(prims); TK_COPY(meshes); TK_COPY(face_idx); TK_COPY(normals); TK_COPY(uvs);
     TK_COPY(texels); TK_COPY(materials); TK_COPY(images); TK_COPY(lights); TK_COPY(light_pmf); TK_COPY(light_cdf);
     TK_COPY(inst_trace); TK_COPY(inst_shade); TK_COPY(env_marginal); TK_COPY(env_conditional); TK_COPY(env_guide_m);
     TK_COPY(env_guide_c);
@@ -1186,12 +1204,12 @@ template <class R> int replicate_t(const SceneT<R> &a, int a_dev, SceneT<R> &b, 
     b.host.env = a.host.env;
     b.host.stats = a.host.stats;
     b.host.n_material_tags = a.host.n_material_tags, b.host.tag_mask = a.host.tag_mask, b.host.single_tag = a.host.single_tag;
-    b.host.q_inflation = a.host.q_inflation, b.host.root_child = a.host.root_child;
+    b.host.q_inflation = a.host.q_inflation, b.host.root_child = a.host.root_child, b.host.node_width = a.host.node_width;
     b.host.n_blas = a.host.n_blas, b.host.blas_nodes = a.host.blas_nodes, b.host.blas_prims = a.host.blas_prims;
     for (int k = 0; k < 3; k++) b.host.grid_lo[k] = a.host.grid_lo[k], b.host.grid_step[k] = a.host.grid_step[k], b.host.background[k] = a.host.background[k];
     DeviceScene<R> &d = b.dev;
     d = a.dev;  // the plain values; then the pointers of this device
-    d.nodes = b.nodes.p, d.qnodes = a.dev.qnodes ? b.qnodes.p : nullptr, d.prims = b.prims.p, d.shapes = nullptr;
+    d.nodes = b.nodes.p, d.qnodes = a.dev.qnodes ? b.qnodes.p : nullptr, d.qnodes8 = b.qnodes8.p, d.prims = b.prims.p, d.shapes = nullptr;
     d.meshes = b.meshes.p, d.face_idx = b.face_idx.p, d.normals = b.normals.p, d.uvs = b.uvs.p, d.texels = b.texels.p;
     d.materials = b.materials.p, d.images = b.images.p, d.lights = b.lights.p, d.light_pmf = b.light_pmf.p, d.light_cdf = b.light_cdf.p;
     d.inst_trace = b.inst_trace.p, d.inst_shade = b.inst_shade.p;

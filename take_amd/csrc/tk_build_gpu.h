@@ -10,7 +10,7 @@
 //   k_refit          bottom-up boxes, second arrival at a node computes it (agent-scope fences around the flag)
 //   k_collapse       BVH2 -> 4-wide nodes, one launch per tree level, breadth-first numbering (same layout and the
 //                    same "open the child with the largest area" rule as the host collapse, tk_bvh.h)
-//   k_quantise       64-byte compressed nodes on the 16-bit scene grid (same rounding rules as quantise_nodes)
+//   k_quantise       64-byte compressed nodes on the 15-bit scene grid (same rounding rules as quantise_nodes)
 //   k_permute        primitive and shading records into leaf order
 //
 // The tree is an LBVH: built in milliseconds, but without the SAH its boxes overlap more, so traversal visits more
@@ -24,6 +24,7 @@
 #include <cmath>
 #include <limits>
 
+#include "tk_bvh.h"
 #include "tk_scene.h"
 
 namespace tk {
@@ -311,33 +312,8 @@ __global__ void __launch_bounds__(BLK) k_collapse(int level, const int *__restri
     }
 }
 
-struct Grid {
-    float lo[3], step[3];
-    double delta[3];
-};
-// The 16-bit scene grid for compressed nodes over [lo, hi] (same rule as tk_bvh.h: quantise_nodes).
-inline Grid make_grid(const double lo_in[3], const double hi_in[3]) {
-    Grid g;
-    for (int a = 0; a < 3; a++) {
-        double lo = lo_in[a], hi = hi_in[a];
-        if (!(lo <= hi)) lo = hi = 0.0;
-        double ext = hi - lo;
-        if (!(ext > 0)) ext = std::max(std::fabs(lo), 1.0) * 1e-6;
-        float step = (float)(ext * (1.0 + 1e-5) / 65535.0);
-        float p = 0;
-        for (;; step = std::nextafterf(step * 1.0001f, std::numeric_limits<float>::infinity())) {
-            g.delta[a] = 65535.0 * (double)step * 0x1p-21;
-            const double x = lo - g.delta[a];
-            p = (float)x;
-            if ((double)p > x) p = std::nextafterf(p, -std::numeric_limits<float>::infinity());
-            if ((double)p + 65535.0 * (double)step >= hi + g.delta[a]) break;
-        }
-        g.lo[a] = p, g.step[a] = step;
-    }
-    return g;
-}
 // acc[0] += sum of min(decoded area / true area, 100) over child boxes, acc[1] += number of child boxes
-__global__ void __launch_bounds__(BLK) k_quantise(const Node4<float> *__restrict__ nodes, int n, Grid g, QNode4 *out, double *acc) {
+__global__ void __launch_bounds__(BLK) k_quantise(const Node4<float> *__restrict__ nodes, int n, QGrid g, QNode4 *out, double *acc) {
     const int i = blockIdx.x * BLK + threadIdx.x;
     double ratio = 0, slots = 0;
     if (i < n) {
@@ -345,20 +321,15 @@ __global__ void __launch_bounds__(BLK) k_quantise(const Node4<float> *__restrict
         QNode4 q;
         for (int c = 0; c < 4; c++) {
             q.c[c].child = nd.c[c].child;
-            q.c[c].q[0] = q.c[c].q[1] = q.c[c].q[2] = 0;
+            q.c[c].q[0] = q.c[c].q[1] = q.c[c].q[2] = (uint32_t)Q_MAX;  // empty slot: inverted box (tk_bvh.h: quantise_nodes)
             if (nd.c[c].child == CHILD_EMPTY) continue;
             double et[3], eq[3];
             for (int a = 0; a < 3; a++) {
-                const double p = g.lo[a], step = g.step[a];
-                const double l = (double)nd.c[c].bmin[a] - g.delta[a], h = (double)nd.c[c].bmax[a] + g.delta[a];
-                long long ql = (long long)floor((l - p) / step);
-                while (p + (double)ql * step > l) ql--;
-                long long qh = (long long)ceil((h - p) / step);
-                while (p + (double)qh * step < h) qh++;
-                ql = ql < 0 ? 0 : ql, qh = qh > 65535 ? 65535 : qh;  // no-ops: the grid spans the scene
+                long long ql, qh;
+                qgrid_snap(g, a, (double)nd.c[c].bmin[a] - g.delta[a], (double)nd.c[c].bmax[a] + g.delta[a], ql, qh);
                 q.c[c].q[a] = (uint32_t)ql | ((uint32_t)qh << 16);
                 et[a] = (double)nd.c[c].bmax[a] - (double)nd.c[c].bmin[a];
-                eq[a] = (double)(qh - ql) * step;
+                eq[a] = (double)(qh - ql) * (double)g.step[a];
             }
             const double at = et[0] * et[1] + et[1] * et[2] + et[2] * et[0], aq = eq[0] * eq[1] + eq[1] * eq[2] + eq[2] * eq[0];
             ratio += at > 0 ? fmin(aq / at, 100.0) : (aq > 0 ? 100.0 : 1.0);

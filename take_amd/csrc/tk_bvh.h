@@ -194,12 +194,18 @@ struct WideBvhStats {
     double sah = 0;  // expected (node fetches, primitive tests) per random ray, for DESIGN figures
 };
 
-// Collapse a BVH2 into Node4<R> records (breadth-first) and the leaf-ordered primitive permutation.
+// Collapse a BVH2 into W-wide records (breadth-first) and the leaf-ordered primitive permutation.
 // prim_order[i] = index into the BuildPrim array (post-build order) of the i-th primitive in leaf order.
 // `bprims` (the builder's primitive array, post-build order): needed only for two-level scenes, to turn the
 // single-primitive leaf of an instance into an instance word.
-template <class R>
-int32_t collapse_to_wide(const std::vector<Bvh2Node> &n2, int root, std::vector<Node4<R>> &out,
+// Slot order.  W = 4: largest box first = the visiting order of the 4-wide shadow-ray kernel, which does not rank
+// its children (any occluder ends the ray): a shadow ray dives into the child it is most likely to be stopped in
+// (1M soup, host model of the kernel's order: 34.2 -> 17.3 node steps per shadow ray); closest-hit traversal ranks
+// by entry distance and does not care.  W = 8: slot s = the octant of the node the child lies in (bit a of s: high
+// side of axis a), by a greedy auction on sum_a (+-)(child centre - node centre)_a, so that a ray visits the
+// slots in the order s ^ (octant of its direction) roughly front to back (tk_scene.h: QNode8).
+template <class R, int W>
+int32_t collapse_to_wide(const std::vector<Bvh2Node> &n2, int root, std::vector<NodeW<R, W>> &out,
                          std::vector<int32_t> &prim_order, WideBvhStats &stats, const std::vector<BuildPrim> *bprims = nullptr) {
     out.clear();
     prim_order.clear();
@@ -227,11 +233,11 @@ int32_t collapse_to_wide(const std::vector<Bvh2Node> &n2, int root, std::vector<
     while (head < queue.size()) {
         const Item it = queue[head];
         const size_t self = head++;
-        int kids[4];
+        int kids[W];
         int nk = 0;
         kids[nk++] = n2[it.n2].left;
         kids[nk++] = n2[it.n2].right;
-        while (nk < 4) {
+        while (nk < W) {
             int best = -1;
             double best_area = -1;
             for (int i = 0; i < nk; i++) {
@@ -247,12 +253,10 @@ int32_t collapse_to_wide(const std::vector<Bvh2Node> &n2, int root, std::vector<
             kids[best] = n2[open].left;
             kids[nk++] = n2[open].right;
         }
-        // Slot order = visiting order of the shadow-ray kernel, which does not rank its children (any occluder ends the
-        // ray): largest box first.  A shadow ray dives into the child it is most likely to be stopped in instead of
-        // the one the builder happened to emit first (1M soup, host model of the kernel's order: 34.2 -> 17.3 node
-        // steps per shadow ray).  Closest-hit traversal ranks by entry distance and does not care.
-        {
-            double ar[4];
+        int slot_kid[W];  // the child of each slot, -1 = empty
+        for (int i = 0; i < W; i++) slot_kid[i] = -1;
+        if (W == 4) {
+            double ar[W];
             for (int i = 0; i < nk; i++) {
                 Bounds b;
                 b.grow(n2[kids[i]].bmin, n2[kids[i]].bmax);
@@ -260,12 +264,43 @@ int32_t collapse_to_wide(const std::vector<Bvh2Node> &n2, int root, std::vector<
             }
             for (int i = 1; i < nk; i++)
                 for (int j = i; j > 0 && ar[j] > ar[j - 1]; j--) std::swap(ar[j], ar[j - 1]), std::swap(kids[j], kids[j - 1]);
-        }
-        Node4<R> node;
-        for (int i = 0; i < 4; i++) {
-            node.c[i].pad = 0;
-            if (i < nk) {
+            for (int i = 0; i < nk; i++) slot_kid[i] = kids[i];
+        } else {
+            const Bvh2Node &pn = n2[it.n2];
+            double gain[W][W];
+            for (int i = 0; i < nk; i++) {
                 const Bvh2Node &c = n2[kids[i]];
+                for (int s = 0; s < W; s++) {
+                    double v = 0;
+                    for (int a = 0; a < 3; a++) {
+                        const double d = 0.5 * (c.bmin[a] + c.bmax[a]) - 0.5 * (pn.bmin[a] + pn.bmax[a]);
+                        v += ((s >> a) & 1) ? d : -d;
+                    }
+                    gain[i][s] = v;
+                }
+            }
+            bool kid_used[W] = {false}, slot_used[W] = {false};
+            for (int r = 0; r < nk; r++) {
+                int bi = -1, bs = -1;
+                double bv = -std::numeric_limits<double>::infinity();
+                for (int i = 0; i < nk; i++)
+                    if (!kid_used[i])
+                        for (int s = 0; s < W; s++)
+                            if (!slot_used[s] && gain[i][s] > bv) bv = gain[i][s], bi = i, bs = s;
+                if (bi < 0) {  // (NaN boxes: any free pair)
+                    for (int i = 0; i < nk && bi < 0; i++)
+                        if (!kid_used[i]) bi = i;
+                    for (int s = 0; s < W && bs < 0; s++)
+                        if (!slot_used[s]) bs = s;
+                }
+                kid_used[bi] = true, slot_used[bs] = true, slot_kid[bs] = kids[bi];
+            }
+        }
+        NodeW<R, W> node;
+        for (int i = 0; i < W; i++) {
+            node.c[i].pad = 0;
+            if (slot_kid[i] >= 0) {
+                const Bvh2Node &c = n2[slot_kid[i]];
                 for (int a = 0; a < 3; a++) {
                     node.c[i].bmin[a] = round_down(c.bmin[a], R());
                     node.c[i].bmax[a] = round_up(c.bmax[a], R());
@@ -274,7 +309,7 @@ int32_t collapse_to_wide(const std::vector<Bvh2Node> &n2, int root, std::vector<
                     node.c[i].child = emit_leaf(c);
                 } else {
                     node.c[i].child = (int32_t)queue.size();
-                    queue.push_back({kids[i], it.depth + 1});
+                    queue.push_back({slot_kid[i], it.depth + 1});
                     out.emplace_back();
                 }
             } else {
@@ -290,65 +325,72 @@ int32_t collapse_to_wide(const std::vector<Bvh2Node> &n2, int root, std::vector<
     return 0;  // root node index
 }
 
-// Compressed copy of the nodes (QNode4, tk_scene.h) on one 16-bit grid over the union of all child boxes.  (f64
+// Compressed copy of the nodes (QNode4, tk_scene.h) on one 15-bit grid over the union of all child boxes.  (f64
 // scenes traverse the same compressed nodes: a conservative box test may be done in any precision — only the
 // primitive tests decide a hit, and those stay in double.)
-// Per axis: step = extent / 65535 rounded up to a float with slack, every child plane is moved outwards by
-// delta = 65535 * step * 2^-21 and then snapped outwards to the grid.  delta pays for the rounding of the grid-space
-// slab test (tk_traverse.h: qray_make); the checks below are on exact values (a float plus a 16-bit multiple of a
-// float is exact in double to ~1e-16 relative, nothing next to delta).
+// Per axis: step = extent / Q_MAX rounded up to a float with slack, every child plane is moved outwards by
+// delta = Q_MAX * step * 2^-20 and then snapped outwards to the grid; plane(q) = grid_lo + (Q_BIAS + q) * step, i.e.
+// grid_lo is one grid extent below the lowest plane (the bias makes the device's float image of q exact, tk_scene.h).
+// delta pays for the rounding of the grid-space slab test (tk_traverse.h: qray_make: <= 0.75 * 2^-21 extent for
+// origins within two extents of the scene); the checks below are on exact values (a float plus a 17-bit multiple of
+// a float is exact in double to ~1e-16 relative, nothing next to delta).
 // Returns the mean over all child boxes of (decoded half-area / true half-area), each ratio capped at 100: how much
 // more often a box is entered by the rays that reach its parent.  (Not weighted by absolute area: a cluster of
 // small primitives inside a huge scene is exactly where the grid is too coarse, and where the camera usually
 // looks.)  The caller keeps the full-width nodes when it is large.
-template <class R>
-inline double quantise_nodes(const std::vector<Node4<R>> &in, std::vector<QNode4> &out, float grid_lo[3],
-                             float grid_step[3]) {
-    out.assign(in.size(), QNode4{});
-    const double inf = std::numeric_limits<double>::infinity();
-    double lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf}, delta[3];
-    for (const Node4<R> &nd : in)
-        for (int i = 0; i < 4; i++)
-            if (nd.c[i].child != CHILD_EMPTY)
-                for (int a = 0; a < 3; a++) lo[a] = std::min(lo[a], (double)nd.c[i].bmin[a]), hi[a] = std::max(hi[a], (double)nd.c[i].bmax[a]);
-    auto float_down = [](double x) {
-        float f = (float)x;
-        if ((double)f > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
-        return f;
-    };
+// the grid over [lo_in, hi_in] (shared by the host quantiser and the device one, tk_build_gpu.h)
+inline QGrid make_qgrid(const double lo_in[3], const double hi_in[3]) {
+    QGrid g;
     for (int a = 0; a < 3; a++) {
-        if (!(lo[a] <= hi[a])) lo[a] = hi[a] = 0.0;
-        double ext = hi[a] - lo[a];
-        if (!(ext > 0)) ext = std::max(std::fabs(lo[a]), 1.0) * 1e-6;  // flat scene on this axis: any small grid will do
-        float step = (float)(ext * (1.0 + 1e-5) / 65535.0);
+        double lo = lo_in[a], hi = hi_in[a];
+        if (!(lo <= hi)) lo = hi = 0.0;
+        double ext = hi - lo;
+        if (!(ext > 0)) ext = std::max(std::fabs(lo), 1.0) * 1e-6;  // flat scene on this axis: any small grid will do
+        float step = (float)(ext * (1.0 + 1e-5) / (double)Q_MAX);
         float p = 0;
         for (;; step = std::nextafterf(step * 1.0001f, std::numeric_limits<float>::infinity())) {
-            delta[a] = 65535.0 * (double)step * 0x1p-21;
-            p = float_down(lo[a] - delta[a]);
-            if ((double)p + 65535.0 * (double)step >= hi[a] + delta[a]) break;
+            g.delta[a] = (double)Q_MAX * (double)step * 0x1p-20;
+            const double x = lo - g.delta[a] - (double)Q_BIAS * (double)step;
+            p = (float)x;
+            if ((double)p > x) p = std::nextafterf(p, -std::numeric_limits<float>::infinity());
+            if ((double)p + (double)(Q_BIAS + Q_MAX) * (double)step >= hi + g.delta[a]) break;
         }
-        grid_lo[a] = p, grid_step[a] = step;
+        g.lo[a] = p, g.step[a] = step;
     }
+    return g;
+}
+template <class R, int W>
+inline double quantise_nodes(const std::vector<NodeW<R, W>> &in, std::vector<QNodeW<W>> &out, float grid_lo[3],
+                             float grid_step[3]) {
+    out.assign(in.size(), QNodeW<W>{});
+    const double inf = std::numeric_limits<double>::infinity();
+    double lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+    for (const NodeW<R, W> &nd : in)
+        for (int i = 0; i < W; i++)
+            if (nd.c[i].child != CHILD_EMPTY)
+                for (int a = 0; a < 3; a++) lo[a] = std::min(lo[a], (double)nd.c[i].bmin[a]), hi[a] = std::max(hi[a], (double)nd.c[i].bmax[a]);
+    const QGrid g = make_qgrid(lo, hi);
+    for (int a = 0; a < 3; a++) grid_lo[a] = g.lo[a], grid_step[a] = g.step[a];
     double ratio_sum = 0;
     int64_t n_slots = 0;
     for (size_t n = 0; n < in.size(); n++) {
-        const Node4<R> &nd = in[n];
-        QNode4 q{};
-        for (int i = 0; i < 4; i++) {
+        const NodeW<R, W> &nd = in[n];
+        QNodeW<W> q{};
+        for (int i = 0; i < W; i++) {
             q.c[i].child = nd.c[i].child;
-            if (nd.c[i].child == CHILD_EMPTY) continue;
+            if (nd.c[i].child == CHILD_EMPTY) {
+                // an empty slot holds an inverted box (lo = Q_MAX, hi = 0 on every axis): it fails the slab test by a
+                // whole grid extent (the kernels still look at the child word: tk_traverse.h)
+                for (int a = 0; a < 3; a++) q.c[i].q[a] = (uint32_t)Q_MAX;
+                continue;
+            }
             double et[3], eq[3];
             for (int a = 0; a < 3; a++) {
-                const double p = grid_lo[a], step = grid_step[a];
-                const double l = (double)nd.c[i].bmin[a] - delta[a], h = (double)nd.c[i].bmax[a] + delta[a];
-                long ql = (long)std::floor((l - p) / step);
-                while (p + ql * step > l) ql--;
-                long qh = (long)std::ceil((h - p) / step);
-                while (p + qh * step < h) qh++;
-                ql = std::max(ql, 0L), qh = std::min(qh, 65535L);  // no-ops by construction of grid_lo and grid_step
+                long long ql, qh;
+                qgrid_snap(g, a, (double)nd.c[i].bmin[a] - g.delta[a], (double)nd.c[i].bmax[a] + g.delta[a], ql, qh);
                 q.c[i].q[a] = (uint32_t)ql | ((uint32_t)qh << 16);
                 et[a] = (double)nd.c[i].bmax[a] - (double)nd.c[i].bmin[a];
-                eq[a] = (double)(qh - ql) * step;
+                eq[a] = (double)(qh - ql) * (double)g.step[a];
             }
             const double at = et[0] * et[1] + et[1] * et[2] + et[2] * et[0], aq = eq[0] * eq[1] + eq[1] * eq[2] + eq[2] * eq[0];
             ratio_sum += at > 0 ? std::min(aq / at, 100.0) : (aq > 0 ? 100.0 : 1.0);

@@ -22,6 +22,9 @@ namespace tk {
 template <class R> struct HostScene {
     std::vector<Node4<R>> nodes;
     std::vector<QNode4> qnodes;  // compressed copy of nodes (empty = not in use)
+    std::vector<Node8<R>> nodes8; // the 8-wide tree at full width: the source of qnodes8 (checks only; never uploaded)
+    std::vector<QNode8> qnodes8; // the 8-wide compressed tree (then nodes and qnodes are empty)
+    int node_width = 4;          // 4 or 8
     float grid_lo[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1};
     double q_inflation = 1.0;    // mean surface-area inflation of the compressed child boxes (1 = none)
     std::vector<PrimRec<R>> prims;
@@ -52,10 +55,11 @@ template <class R> struct HostScene {
         DeviceScene<R> d{};
         d.nodes = nodes.data();
         d.qnodes = qnodes.empty() ? nullptr : qnodes.data();
+        d.qnodes8 = qnodes8.empty() ? nullptr : qnodes8.data();
         for (int a = 0; a < 3; a++) d.grid_lo[a] = grid_lo[a], d.grid_step[a] = grid_step[a];
         d.prims = prims.data();
         d.root_child = root_child;
-        d.n_nodes = (int32_t)nodes.size();
+        d.n_nodes = (int32_t)stats.n_nodes;
         d.shapes = shapes.data();
         d.meshes = meshes.data();
         d.face_idx = face_idx.data();
@@ -195,6 +199,190 @@ inline bool env_tables(const double *rgb, int w, int h, std::vector<double> &mar
     for (int y = 0; y < h; y++) marg[y] /= total;
     marg[h] = 1.0;
     return true;
+}
+
+// The host-side trees of a scene, W-wide: the top-level tree over `bp` (shapes, plus one box per placement of a
+// two-level scene), the prototype trees, their compressed form.  Out: `nodes` (full width), `qnodes` (compressed; empty
+// when the grid is too coarse or on request), hs.root_child / stats / grid / inst_* / the prototypes' records in
+// hs.prims, `order` (leaf order of the top-level tree's primitives as indices into bp).
+template <class R, int W>
+std::string build_host_trees(const TakeSceneDesc &d, HostScene<R> &hs, std::vector<BuildPrim> &bp, int leaf_size, int threads,
+                             const std::string &fmt, int64_t ns, std::vector<int32_t> &order, std::vector<NodeW<R, W>> &nodes,
+                             std::vector<QNodeW<W>> &qnodes) {
+    // ---- two-level scenes (EXTENSION, TakeInstance): one tree per prototype mesh in object space ("BLAS"), their
+    // nodes and primitive records appended behind the top-level tree's; an instance enters the top-level build
+    // as one box and leaves it as an instance word.
+    struct Blas {
+        std::vector<NodeW<R, W>> nodes;
+        std::vector<PrimRec<R>> prims;
+        int32_t root_child = CHILD_EMPTY;
+        double lo[3], hi[3];
+        int depth = 0;
+    };
+    std::vector<Blas> blas;
+    std::vector<int> blas_of_mesh(d.n_meshes, -1);
+    std::vector<int> inst_blas(d.n_instances, -1);
+    int max_blas_depth = 0;
+    int64_t shape_next = ns;
+    hs.inst_trace.assign(d.n_instances, InstTrace<R>{});
+    hs.inst_shade.assign(d.n_instances, InstShade<R>{});
+    for (int64_t i = 0; i < d.n_instances; i++) {
+        const TakeInstance &in = d.instances[i];
+        if (in.mesh_id < 0 || in.mesh_id >= d.n_meshes) return "instance " + std::to_string(i) + ": bad mesh id";
+        if (in.material_id < -1 || in.material_id >= d.n_materials) return "instance " + std::to_string(i) + ": bad material id";
+        const TakeMesh &m = d.meshes[in.mesh_id];
+        if (m.n_faces <= 0) return "instance " + std::to_string(i) + ": empty prototype mesh";
+        if (blas_of_mesh[in.mesh_id] < 0) {
+            blas_of_mesh[in.mesh_id] = (int)blas.size();
+            blas.emplace_back();
+            Blas &b = blas.back();
+            const MeshInfo &mi = hs.meshes[in.mesh_id];
+            std::vector<PrimRec<R>> brecs(m.n_faces);
+            std::vector<BuildPrim> bbp(m.n_faces);
+            for (int a = 0; a < 3; a++) b.lo[a] = std::numeric_limits<double>::infinity(), b.hi[a] = -b.lo[a];
+            for (int64_t f = 0; f < m.n_faces; f++) {
+                PrimRec<R> &p = brecs[f];
+                p = PrimRec<R>{};
+                const int32_t *idx = m.indices + 3 * f;
+                Vec3<R> v[3];
+                for (int k = 0; k < 3; k++)
+                    v[k] = {R(m.positions[3 * (int64_t)idx[k]]), R(m.positions[3 * (int64_t)idx[k] + 1]),
+                            R(m.positions[3 * (int64_t)idx[k] + 2])};
+                const Vec3<R> e1 = v[1] - v[0], e2 = v[2] - v[0];
+                p.a[0] = v[0].x, p.a[1] = v[0].y, p.a[2] = v[0].z;
+                p.a[3] = e1.x, p.a[4] = e1.y, p.a[5] = e1.z;
+                p.a[6] = e2.x, p.a[7] = e2.y, p.a[8] = e2.z;
+                p.shape_id = (int32_t)f;  // local: the shape id of a hit is InstShade::shape_base + this
+                p.meta = PRIM_TRIANGLE | (hs.materials[m.material_id].tag << 8);
+                p.material = m.material_id, p.area_light = -1, p.nidx = -1, p.mesh = in.mesh_id;
+                if (mi.nbase >= 0 || mi.uvbase >= 0) p.nidx = mi.fbase + (int32_t)f, p.meta |= META_HAS_ATTR;
+                for (int a = 0; a < 3; a++) {
+                    const double x0 = (double)(&v[0].x)[a], x1 = (double)(&v[1].x)[a], x2 = (double)(&v[2].x)[a];
+                    bbp[f].bmin[a] = std::min(x0, std::min(x1, x2));
+                    bbp[f].bmax[a] = std::max(x0, std::max(x1, x2));
+                    b.lo[a] = std::min(b.lo[a], bbp[f].bmin[a]), b.hi[a] = std::max(b.hi[a], bbp[f].bmax[a]);
+                }
+                bbp[f].id = (int32_t)f;
+            }
+            Bvh2Builder bb(bbp, leaf_size, threads);
+            const int broot = bb.build();
+            std::vector<int32_t> border;
+            WideBvhStats bst;
+            b.root_child = collapse_to_wide<R, W>(bb.nodes(), broot, b.nodes, border, bst);
+            b.depth = bst.depth;
+            b.prims.resize(border.size());
+            for (size_t k = 0; k < border.size(); k++) b.prims[k] = brecs[bbp[border[k]].id];
+            order_coincident(b.prims, 0, b.prims.size());
+            max_blas_depth = std::max(max_blas_depth, b.depth);
+        }
+        inst_blas[i] = blas_of_mesh[in.mesh_id];
+        const Blas &b = blas[inst_blas[i]];
+        // transforms: forward linear part for shading, inverse (in double) for the ray
+        const double *M = in.xform;
+        const double a00 = M[0], a01 = M[1], a02 = M[2], a10 = M[4], a11 = M[5], a12 = M[6], a20 = M[8], a21 = M[9], a22 = M[10];
+        const double det = a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
+        if (!(std::fabs(det) > 1e-300)) return "instance " + std::to_string(i) + ": singular transform";
+        const double inv[9] = {(a11 * a22 - a12 * a21) / det, (a02 * a21 - a01 * a22) / det, (a01 * a12 - a02 * a11) / det,
+                               (a12 * a20 - a10 * a22) / det, (a00 * a22 - a02 * a20) / det, (a02 * a10 - a00 * a12) / det,
+                               (a10 * a21 - a11 * a20) / det, (a01 * a20 - a00 * a21) / det, (a00 * a11 - a01 * a10) / det};
+        InstTrace<R> &it = hs.inst_trace[i];
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) it.inv[4 * r + c] = R(inv[3 * r + c]);
+            it.inv[4 * r + 3] = R(-(inv[3 * r] * M[3] + inv[3 * r + 1] * M[7] + inv[3 * r + 2] * M[11]));
+        }
+        InstShade<R> &is = hs.inst_shade[i];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) is.fwd[3 * r + c] = R(M[4 * r + c]);
+        is.material = in.material_id >= 0 ? in.material_id : m.material_id;
+        is.tag = hs.materials[is.material].tag;
+        is.shape_base = (int32_t)shape_next;
+        shape_next += m.n_faces;
+        if (shape_next >= (int64_t)1 << 31) return "too many instanced faces for 32-bit shape ids";
+        // world box of the placement: the object box's corners under the transform, padded for the rounding of
+        // the transformed ray (the specification is the flattened geometry to fp rounding, see take_hip.h)
+        BuildPrim ib;
+        ib.id = -(int32_t)(i + 1);
+        for (int a = 0; a < 3; a++) ib.bmin[a] = std::numeric_limits<double>::infinity(), ib.bmax[a] = -ib.bmin[a];
+        double mag = 0;
+        for (int c8 = 0; c8 < 8; c8++) {
+            const double px = (c8 & 1) ? b.hi[0] : b.lo[0], py = (c8 & 2) ? b.hi[1] : b.lo[1], pz = (c8 & 4) ? b.hi[2] : b.lo[2];
+            for (int a = 0; a < 3; a++) {
+                const double w = M[4 * a] * px + M[4 * a + 1] * py + M[4 * a + 2] * pz + M[4 * a + 3];
+                ib.bmin[a] = std::min(ib.bmin[a], w), ib.bmax[a] = std::max(ib.bmax[a], w);
+                mag = std::max(mag, std::fabs(w));
+            }
+        }
+        const double pad = mag * (sizeof(R) == 4 ? 4e-6 : 1e-13);
+        for (int a = 0; a < 3; a++) ib.bmin[a] -= pad, ib.bmax[a] += pad;
+        bp.push_back(ib);
+    }
+
+    Bvh2Builder builder(bp, leaf_size, threads);
+    const int root = builder.build();
+    hs.root_child = collapse_to_wide<R, W>(builder.nodes(), root, nodes, order, hs.stats, d.n_instances > 0 ? &bp : nullptr);
+    int32_t top_prims = (int32_t)order.size();
+    // append the prototype trees: node indices and leaf ranges become global
+    const size_t top_nodes = nodes.size();
+    std::vector<size_t> blas_node_base(blas.size()), blas_prim_base(blas.size());
+    {
+        size_t nb = top_nodes, pb = (size_t)top_prims;
+        for (size_t k = 0; k < blas.size(); k++) {
+            blas_node_base[k] = nb, blas_prim_base[k] = pb;
+            nb += blas[k].nodes.size(), pb += blas[k].prims.size();
+        }
+        if (pb >= ((size_t)1 << 28)) return "too many primitive records for the 4-wide leaf encoding (2^28)";
+        nodes.reserve(nb);
+        for (size_t k = 0; k < blas.size(); k++) {
+            auto fix = [&](int32_t c) -> int32_t {
+                if (c == CHILD_EMPTY) return c;
+                if (c >= 0) return c + (int32_t)blas_node_base[k];
+                return make_leaf(leaf_first(c) + (int32_t)blas_prim_base[k], leaf_count(c));
+            };
+            for (NodeW<R, W> nd : blas[k].nodes) {
+                for (int j = 0; j < W; j++) nd.c[j].child = fix(nd.c[j].child);
+                nodes.push_back(nd);
+            }
+            blas[k].root_child = fix(blas[k].root_child);
+        }
+        hs.n_blas = (int64_t)blas.size(), hs.blas_nodes = (int64_t)(nb - top_nodes), hs.blas_prims = (int64_t)(pb - top_prims);
+    }
+    hs.stats.n_nodes = (int64_t)nodes.size();
+    hs.stats.depth += max_blas_depth;  // the traversal stack holds both levels (+ one return marker)
+    for (int64_t i = 0; i < d.n_instances; i++) hs.inst_trace[i].root_child = blas[inst_blas[i]].root_child;
+
+    qnodes.clear();
+    {
+        // Both precisions traverse the 64-byte compressed nodes unless the 16-bit grid is too coarse for the
+        // geometry (child boxes growing by more than 10 % in area on average: a scene mixing scales by >1e4), or on request
+        // (TAKE_HIP_NODES=wide / =q16: A/B runs).  In f64 scenes only the box tests use them (conservative, so
+        // exactness is not at stake); hits are decided by the double-precision primitive tests.  Every tree of a
+        // two-level scene has its own grid (the top-level one is the scene's, a prototype's is in its InstTrace).
+        if (fmt != "wide" && !nodes.empty()) {
+            std::vector<NodeW<R, W>> part(nodes.begin(), nodes.begin() + top_nodes);
+            std::vector<QNodeW<W>> q;
+            hs.q_inflation = top_nodes ? quantise_nodes<R, W>(part, q, hs.grid_lo, hs.grid_step) : 1.0;
+            qnodes = q;
+            std::vector<std::array<float, 6>> grids(blas.size());
+            for (size_t k = 0; k < blas.size(); k++) {
+                part.assign(nodes.begin() + blas_node_base[k], nodes.begin() + blas_node_base[k] + blas[k].nodes.size());
+                float glo[3], gst[3];
+                const double infl = part.empty() ? 1.0 : quantise_nodes<R, W>(part, q, glo, gst);
+                if (part.empty()) q.clear(), glo[0] = glo[1] = glo[2] = 0, gst[0] = gst[1] = gst[2] = 1;
+                hs.q_inflation = std::max(hs.q_inflation, infl);
+                qnodes.insert(qnodes.end(), q.begin(), q.end());
+                grids[k] = {glo[0], glo[1], glo[2], gst[0], gst[1], gst[2]};
+            }
+            for (int64_t i = 0; i < d.n_instances; i++)
+                for (int a = 0; a < 3; a++)
+                    hs.inst_trace[i].grid_lo[a] = grids[inst_blas[i]][a], hs.inst_trace[i].grid_step[a] = grids[inst_blas[i]][3 + a];
+            if (hs.q_inflation > 1.10 && fmt != "q16") qnodes.clear();
+        }
+    }
+    // primitive records: the top-level tree's in leaf order, then each prototype's
+    hs.prims.resize((size_t)top_prims + (size_t)hs.blas_prims);
+    for (size_t k = 0; k < blas.size(); k++)
+        std::copy(blas[k].prims.begin(), blas[k].prims.end(), hs.prims.begin() + blas_prim_base[k]);
+    return "";
 }
 
 // what prepare_scene leaves to the device (TAKE_BUILDER_DEVICE_LBVH): PREP_ALL = nothing (records, host SAH tree);
@@ -504,7 +692,8 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
         order.resize((size_t)ns);
         for (size_t k = 0; k < order.size(); k++) order[k] = (int32_t)k;
         hs.nodes.clear();
-        hs.qnodes.clear();
+        hs.qnodes.clear(), hs.qnodes8.clear(), hs.nodes8.clear();
+        hs.node_width = 4;
         hs.inst_trace.clear(), hs.inst_shade.clear();
         hs.n_blas = hs.blas_nodes = hs.blas_prims = 0;
         hs.root_child = CHILD_EMPTY;
@@ -519,179 +708,32 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
         const char *fmt_env = std::getenv("TAKE_HIP_NODES");
         const std::string fmt = fmt_env ? fmt_env : "";
 
-        // ---- two-level scenes (EXTENSION, TakeInstance): one tree per prototype mesh in object space ("BLAS"), their
-        // nodes and primitive records appended behind the top-level tree's; an instance enters the top-level build
-        // as one box and leaves it as an instance word.
-        struct Blas {
-            std::vector<Node4<R>> nodes;
-            std::vector<PrimRec<R>> prims;
-            int32_t root_child = CHILD_EMPTY;
-            double lo[3], hi[3];
-            int depth = 0;
-        };
-        std::vector<Blas> blas;
-        std::vector<int> blas_of_mesh(d.n_meshes, -1);
-        std::vector<int> inst_blas(d.n_instances, -1);
-        int max_blas_depth = 0;
-        int64_t shape_next = ns;
-        hs.inst_trace.assign(d.n_instances, InstTrace<R>{});
-        hs.inst_shade.assign(d.n_instances, InstShade<R>{});
-        for (int64_t i = 0; i < d.n_instances; i++) {
-            const TakeInstance &in = d.instances[i];
-            if (in.mesh_id < 0 || in.mesh_id >= d.n_meshes) return "instance " + std::to_string(i) + ": bad mesh id";
-            if (in.material_id < -1 || in.material_id >= d.n_materials) return "instance " + std::to_string(i) + ": bad material id";
-            const TakeMesh &m = d.meshes[in.mesh_id];
-            if (m.n_faces <= 0) return "instance " + std::to_string(i) + ": empty prototype mesh";
-            if (blas_of_mesh[in.mesh_id] < 0) {
-                blas_of_mesh[in.mesh_id] = (int)blas.size();
-                blas.emplace_back();
-                Blas &b = blas.back();
-                const MeshInfo &mi = hs.meshes[in.mesh_id];
-                std::vector<PrimRec<R>> brecs(m.n_faces);
-                std::vector<BuildPrim> bbp(m.n_faces);
-                for (int a = 0; a < 3; a++) b.lo[a] = std::numeric_limits<double>::infinity(), b.hi[a] = -b.lo[a];
-                for (int64_t f = 0; f < m.n_faces; f++) {
-                    PrimRec<R> &p = brecs[f];
-                    p = PrimRec<R>{};
-                    const int32_t *idx = m.indices + 3 * f;
-                    Vec3<R> v[3];
-                    for (int k = 0; k < 3; k++)
-                        v[k] = {R(m.positions[3 * (int64_t)idx[k]]), R(m.positions[3 * (int64_t)idx[k] + 1]),
-                                R(m.positions[3 * (int64_t)idx[k] + 2])};
-                    const Vec3<R> e1 = v[1] - v[0], e2 = v[2] - v[0];
-                    p.a[0] = v[0].x, p.a[1] = v[0].y, p.a[2] = v[0].z;
-                    p.a[3] = e1.x, p.a[4] = e1.y, p.a[5] = e1.z;
-                    p.a[6] = e2.x, p.a[7] = e2.y, p.a[8] = e2.z;
-                    p.shape_id = (int32_t)f;  // local: the shape id of a hit is InstShade::shape_base + this
-                    p.meta = PRIM_TRIANGLE | (hs.materials[m.material_id].tag << 8);
-                    p.material = m.material_id, p.area_light = -1, p.nidx = -1, p.mesh = in.mesh_id;
-                    if (mi.nbase >= 0 || mi.uvbase >= 0) p.nidx = mi.fbase + (int32_t)f, p.meta |= META_HAS_ATTR;
-                    for (int a = 0; a < 3; a++) {
-                        const double x0 = (double)(&v[0].x)[a], x1 = (double)(&v[1].x)[a], x2 = (double)(&v[2].x)[a];
-                        bbp[f].bmin[a] = std::min(x0, std::min(x1, x2));
-                        bbp[f].bmax[a] = std::max(x0, std::max(x1, x2));
-                        b.lo[a] = std::min(b.lo[a], bbp[f].bmin[a]), b.hi[a] = std::max(b.hi[a], bbp[f].bmax[a]);
-                    }
-                    bbp[f].id = (int32_t)f;
-                }
-                Bvh2Builder bb(bbp, leaf_size, threads);
-                const int broot = bb.build();
-                std::vector<int32_t> border;
-                WideBvhStats bst;
-                b.root_child = collapse_to_wide<R>(bb.nodes(), broot, b.nodes, border, bst);
-                b.depth = bst.depth;
-                b.prims.resize(border.size());
-                for (size_t k = 0; k < border.size(); k++) b.prims[k] = brecs[bbp[border[k]].id];
-                order_coincident(b.prims, 0, b.prims.size());
-                max_blas_depth = std::max(max_blas_depth, b.depth);
-            }
-            inst_blas[i] = blas_of_mesh[in.mesh_id];
-            const Blas &b = blas[inst_blas[i]];
-            // transforms: forward linear part for shading, inverse (in double) for the ray
-            const double *M = in.xform;
-            const double a00 = M[0], a01 = M[1], a02 = M[2], a10 = M[4], a11 = M[5], a12 = M[6], a20 = M[8], a21 = M[9], a22 = M[10];
-            const double det = a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
-            if (!(std::fabs(det) > 1e-300)) return "instance " + std::to_string(i) + ": singular transform";
-            const double inv[9] = {(a11 * a22 - a12 * a21) / det, (a02 * a21 - a01 * a22) / det, (a01 * a12 - a02 * a11) / det,
-                                   (a12 * a20 - a10 * a22) / det, (a00 * a22 - a02 * a20) / det, (a02 * a10 - a00 * a12) / det,
-                                   (a10 * a21 - a11 * a20) / det, (a01 * a20 - a00 * a21) / det, (a00 * a11 - a01 * a10) / det};
-            InstTrace<R> &it = hs.inst_trace[i];
-            for (int r = 0; r < 3; r++) {
-                for (int c = 0; c < 3; c++) it.inv[4 * r + c] = R(inv[3 * r + c]);
-                it.inv[4 * r + 3] = R(-(inv[3 * r] * M[3] + inv[3 * r + 1] * M[7] + inv[3 * r + 2] * M[11]));
-            }
-            InstShade<R> &is = hs.inst_shade[i];
-            for (int r = 0; r < 3; r++)
-                for (int c = 0; c < 3; c++) is.fwd[3 * r + c] = R(M[4 * r + c]);
-            is.material = in.material_id >= 0 ? in.material_id : m.material_id;
-            is.tag = hs.materials[is.material].tag;
-            is.shape_base = (int32_t)shape_next;
-            shape_next += m.n_faces;
-            if (shape_next >= (int64_t)1 << 31) return "too many instanced faces for 32-bit shape ids";
-            // world box of the placement: the object box's corners under the transform, padded for the rounding of
-            // the transformed ray (the specification is the flattened geometry to fp rounding, see take_hip.h)
-            BuildPrim ib;
-            ib.id = -(int32_t)(i + 1);
-            for (int a = 0; a < 3; a++) ib.bmin[a] = std::numeric_limits<double>::infinity(), ib.bmax[a] = -ib.bmin[a];
-            double mag = 0;
-            for (int c8 = 0; c8 < 8; c8++) {
-                const double px = (c8 & 1) ? b.hi[0] : b.lo[0], py = (c8 & 2) ? b.hi[1] : b.lo[1], pz = (c8 & 4) ? b.hi[2] : b.lo[2];
-                for (int a = 0; a < 3; a++) {
-                    const double w = M[4 * a] * px + M[4 * a + 1] * py + M[4 * a + 2] * pz + M[4 * a + 3];
-                    ib.bmin[a] = std::min(ib.bmin[a], w), ib.bmax[a] = std::max(ib.bmax[a], w);
-                    mag = std::max(mag, std::fabs(w));
-                }
-            }
-            const double pad = mag * (sizeof(R) == 4 ? 4e-6 : 1e-13);
-            for (int a = 0; a < 3; a++) ib.bmin[a] -= pad, ib.bmax[a] += pad;
-            bp.push_back(ib);
-        }
-
-        Bvh2Builder builder(bp, leaf_size, threads);
-        const int root = builder.build();
-        hs.root_child = collapse_to_wide<R>(builder.nodes(), root, hs.nodes, order, hs.stats, d.n_instances > 0 ? &bp : nullptr);
-        int32_t top_prims = (int32_t)order.size();
-        // append the prototype trees: node indices and leaf ranges become global
-        const size_t top_nodes = hs.nodes.size();
-        std::vector<size_t> blas_node_base(blas.size()), blas_prim_base(blas.size());
-        {
-            size_t nb = top_nodes, pb = (size_t)top_prims;
-            for (size_t k = 0; k < blas.size(); k++) {
-                blas_node_base[k] = nb, blas_prim_base[k] = pb;
-                nb += blas[k].nodes.size(), pb += blas[k].prims.size();
-            }
-            if (pb >= ((size_t)1 << 28)) return "too many primitive records for the 4-wide leaf encoding (2^28)";
-            hs.nodes.reserve(nb);
-            for (size_t k = 0; k < blas.size(); k++) {
-                auto fix = [&](int32_t c) -> int32_t {
-                    if (c == CHILD_EMPTY) return c;
-                    if (c >= 0) return c + (int32_t)blas_node_base[k];
-                    return make_leaf(leaf_first(c) + (int32_t)blas_prim_base[k], leaf_count(c));
-                };
-                for (Node4<R> nd : blas[k].nodes) {
-                    for (int j = 0; j < 4; j++) nd.c[j].child = fix(nd.c[j].child);
-                    hs.nodes.push_back(nd);
-                }
-                blas[k].root_child = fix(blas[k].root_child);
-            }
-            hs.n_blas = (int64_t)blas.size(), hs.blas_nodes = (int64_t)(nb - top_nodes), hs.blas_prims = (int64_t)(pb - top_prims);
-        }
-        hs.stats.n_nodes = (int64_t)hs.nodes.size();
-        hs.stats.depth += max_blas_depth;  // the traversal stack holds both levels (+ one return marker)
-        for (int64_t i = 0; i < d.n_instances; i++) hs.inst_trace[i].root_child = blas[inst_blas[i]].root_child;
-
-        hs.qnodes.clear();
-        {
-            // Both precisions traverse the 64-byte compressed nodes unless the 16-bit grid is too coarse for the
-            // geometry (child boxes growing by more than 10 % in area on average: a scene mixing scales by >1e4), or on request
-            // (TAKE_HIP_NODES=wide / =q16: A/B runs).  In f64 scenes only the box tests use them (conservative, so
-            // exactness is not at stake); hits are decided by the double-precision primitive tests.  Every tree of a
-            // two-level scene has its own grid (the top-level one is the scene's, a prototype's is in its InstTrace).
-            if (fmt != "wide" && !hs.nodes.empty()) {
-                std::vector<Node4<R>> part(hs.nodes.begin(), hs.nodes.begin() + top_nodes);
-                std::vector<QNode4> q;
-                hs.q_inflation = top_nodes ? quantise_nodes<R>(part, q, hs.grid_lo, hs.grid_step) : 1.0;
-                hs.qnodes = q;
-                std::vector<std::array<float, 6>> grids(blas.size());
-                for (size_t k = 0; k < blas.size(); k++) {
-                    part.assign(hs.nodes.begin() + blas_node_base[k], hs.nodes.begin() + blas_node_base[k] + blas[k].nodes.size());
-                    float glo[3], gst[3];
-                    const double infl = part.empty() ? 1.0 : quantise_nodes<R>(part, q, glo, gst);
-                    if (part.empty()) q.clear(), glo[0] = glo[1] = glo[2] = 0, gst[0] = gst[1] = gst[2] = 1;
-                    hs.q_inflation = std::max(hs.q_inflation, infl);
-                    hs.qnodes.insert(hs.qnodes.end(), q.begin(), q.end());
-                    grids[k] = {glo[0], glo[1], glo[2], gst[0], gst[1], gst[2]};
-                }
-                for (int64_t i = 0; i < d.n_instances; i++)
-                    for (int a = 0; a < 3; a++)
-                        hs.inst_trace[i].grid_lo[a] = grids[inst_blas[i]][a], hs.inst_trace[i].grid_step[a] = grids[inst_blas[i]][3 + a];
-                if (hs.q_inflation > 1.10 && fmt != "q16") hs.qnodes.clear();
+        // Tree width.  The 4-wide compressed tree is the default.  TAKE_HIP_NODES=q8 selects the 8-wide one (128-byte
+        // nodes, octant-ordered slots; built and measured in round 3: a third fewer node visits per ray — 32.9
+        // instead of 49.2 on the 1M soup — but eight 16-byte loads per lane and visit instead of four, and the vector
+        // L1 charges per load instruction and distinct line: closest hit +16 %, shadow rays +25 % slower);
+        // =wide / =q16 select full-width / forced-compressed 4-wide nodes (A/B runs), and a scene the 15-bit grid is
+        // too coarse for falls back to full-width 4-wide nodes.
+        const bool want8 = fmt == "q8";
+        hs.node_width = 4;
+        std::string terr;
+        if (want8) {
+            std::vector<Node8<R>> &nodes8 = hs.nodes8;
+            terr = build_host_trees<R, 8>(d, hs, bp, leaf_size, threads, fmt, ns, order, nodes8, hs.qnodes8);
+            if (!terr.empty()) return terr;
+            if (!hs.qnodes8.empty() || nodes8.empty()) {
+                hs.node_width = 8;
+                hs.nodes.clear(), hs.qnodes.clear();
+            } else {
+                // (grid too coarse: the full-width fall-back is 4-wide; the placements' boxes are appended again)
+                bp.erase(std::remove_if(bp.begin(), bp.end(), [](const BuildPrim &b) { return b.id < 0; }), bp.end());
             }
         }
-        // primitive records: the top-level tree's in leaf order, then each prototype's
-        hs.prims.resize((size_t)top_prims + (size_t)hs.blas_prims);
-        for (size_t k = 0; k < blas.size(); k++)
-            std::copy(blas[k].prims.begin(), blas[k].prims.end(), hs.prims.begin() + blas_prim_base[k]);
+        if (hs.node_width == 4) {
+            hs.qnodes8.clear(), hs.nodes8.clear();
+            terr = build_host_trees<R, 4>(d, hs, bp, leaf_size, threads, fmt, ns, order, hs.nodes, hs.qnodes);
+            if (!terr.empty()) return terr;
+        }
     }
     if (!host_records) {
         hs.prims.clear();
@@ -715,7 +757,7 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
     return "";
     });
     if (build_bvh) order_coincident(hs.prims, 0, order.size());  // (device build: the stable Morton sort does it)
-    if (3 * hs.stats.depth + 2 > MAX_STACK_ENTRIES) return "BVH too deep for the traversal stack";
+    if ((hs.node_width - 1) * hs.stats.depth + 2 > (hs.node_width == 8 ? MAX_STACK_ENTRIES_W8 : MAX_STACK_ENTRIES)) return "BVH too deep for the traversal stack";
     return "";
 }
 

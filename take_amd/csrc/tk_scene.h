@@ -19,7 +19,8 @@ namespace tk {
 
 constexpr int32_t CHILD_EMPTY = (int32_t)0x80000000;
 constexpr int MAX_LEAF = 4;
-constexpr int MAX_STACK_ENTRIES = 96;  // deepest traversal stack the trace kernels provide (LDS levels + spill area): 3 per tree level + 1
+constexpr int MAX_STACK_ENTRIES_W8 = 192;  // the same for the 8-wide tree (7 entries per level + 1)
+constexpr int MAX_STACK_ENTRIES = 96;  // deepest traversal stack the trace kernels provide (LDS levels + spill area): per tree level 3 entries (4-wide nodes) or 7 (8-wide), + 1
 
 // child word: >= 0 interior node index; < 0 (and != CHILD_EMPTY) leaf: -(1 + first*4 + (count-1)), first < 2^28, i.e.
 // leaf words lie in [-2^30, -1]; the words between CHILD_EMPTY and -2^30 are instance references (two-level scenes:
@@ -40,28 +41,59 @@ template <class R> struct alignas(16) NodeChild {
     int32_t child;
     int32_t pad;
 };
-template <class R> struct alignas(16) Node4 {
-    NodeChild<R> c[4];
+template <class R, int W> struct alignas(16) NodeW {
+    NodeChild<R> c[W];
 };
+template <class R> using Node4 = NodeW<R, 4>;
+template <class R> using Node8 = NodeW<R, 8>;  // (builder-side only: the 8-wide tree is traversed in its compressed form)
 static_assert(sizeof(NodeChild<float>) == 32 && sizeof(Node4<float>) == 128, "one L2 line per f32 node");
 
-// Compressed wide node of the f32 render path: 64 B, two per cache line.  The child boxes are stored on ONE 16-bit
-// grid that spans the whole scene: plane = grid_lo[a] + q * grid_step[a]  (q in 0..65535, DeviceScene::grid_*),
-// rounded outwards, so the decoded box contains the true one (tk_bvh.h: quantise_nodes).  A cell is 1.5e-5 of the
-// scene extent — far below a primitive's size unless the scene mixes scales by more than ~1e4, in which case the
-// builder keeps the full-width nodes (tk_host_scene.h).
+// Compressed wide node of the render paths: 64 B, two per cache line.  The child boxes are stored on ONE 15-bit
+// grid that spans the whole scene: plane = grid_lo[a] + (Q_BIAS + q) * grid_step[a]  (q in 0..Q_MAX,
+// DeviceScene::grid_*), rounded outwards, so the decoded box contains the true one (tk_bvh.h: quantise_nodes).  A cell
+// is 3e-5 of the scene extent — far below a primitive's size unless the scene mixes scales by more than ~1e4, in which
+// case the builder keeps the full-width nodes (tk_host_scene.h).
+// Why 15 bits and the bias: a plane coordinate becomes a float with ONE byte permute (v_perm_b32) and no conversion —
+// the bits 0x48000000 | q << 8 are the float 4 * (Q_BIAS + q) for q < 2^15 (exponent 2^17, q in mantissa bits 8..22) —
+// so the slab test of a slot is 6 permutes + 3 packed fmas (round 2: 3 rotates + 6 conversions + 3 packed fmas on a
+// 16-bit grid).  The bias is folded into grid_lo: grid_lo lies one grid extent below the scene's lower corner.
 // Why: the traversal is bound by the vector L1, which pays one line look-up per ray and per load instruction, and
 // by VALU issue at the same time (profiles/r01_tcp_counters.txt, r01_ubench_gather.txt).  A slot is
 // 16 B: a lane reads its ray's node with 4 x dwordx4 from one line (the pair build: two slots per lane, no exchange),
 // and because the grid is global the ray is moved into grid space once per ray, not once per node.
+constexpr int Q_MAX = 32767;    // largest plane coordinate on the grid
+constexpr int Q_BIAS = 32768;   // plane = grid_lo + (Q_BIAS + q) * grid_step
 struct QChild {
-    uint32_t q[3];  // axis a: lo | hi << 16
+    uint32_t q[3];  // axis a: lo | hi << 16, both in 0..Q_MAX
     int32_t child;  // child word (node index / leaf word / CHILD_EMPTY)
 };
-struct alignas(64) QNode4 {
-    QChild c[4];
+template <int W> struct alignas(16 * W) QNodeW {
+    QChild c[W];
 };
-static_assert(sizeof(QNode4) == 64, "64-byte compressed node");
+using QNode4 = QNodeW<4>;
+// 8-wide compressed node: 128 B = one L2 line = one fabric request per visit, a third fewer visits per ray than the
+// 4-wide tree.  Slot s holds the child that lies on the side (s & 1 ? high : low) of x, (s & 2) of y,
+// (s & 4) of z of the node (tk_bvh.h assigns children to slots by an auction on their centres): a ray visits the slots
+// in the order s ^ octant — front to back as far as one permutation per octant can tell — so a step needs no
+// ranking of eight entry distances, only their minimum.
+using QNode8 = QNodeW<8>;
+static_assert(sizeof(QNode4) == 64 && sizeof(QNode8) == 128, "64- and 128-byte compressed nodes");
+// a quantisation grid as the builders make it (tk_bvh.h: make_qgrid): delta = the outward slack every plane gets
+// before it is snapped to the grid
+struct QGrid {
+    float lo[3], step[3];
+    double delta[3];
+};
+// outward snap of the interval [l, h] (already widened by delta) to plane coordinates of axis a; exact in double (a
+// float plus a 17-bit multiple of a float), the same on the host and on the device
+TK_HD void qgrid_snap(const QGrid &g, int a, double l, double h, long long &ql, long long &qh) {
+    const double base = (double)g.lo[a], step = (double)g.step[a], p = base + (double)Q_BIAS * step;
+    ql = (long long)floor((l - p) / step);
+    while (base + (double)(Q_BIAS + ql) * step > l) ql--;
+    qh = (long long)ceil((h - p) / step);
+    while (base + (double)(Q_BIAS + qh) * step < h) qh++;
+    ql = ql < 0 ? 0 : ql, qh = qh > Q_MAX ? Q_MAX : qh;  // no-ops by construction of the grid
+}
 
 constexpr int32_t PRIM_TRIANGLE = 0;
 constexpr int32_t PRIM_SPHERE = 1;
@@ -168,8 +200,9 @@ template <class R> struct CameraRec {
 // All device pointers of one scene.  Passed to kernels by value.
 template <class R> struct DeviceScene {
     const Node4<R> *nodes;
-    const QNode4 *qnodes;  // f32 only: compressed copy of nodes (same indices); nullptr = traverse the full-width nodes
-    float grid_lo[3], grid_step[3];  // the quantisation grid of qnodes
+    const QNode4 *qnodes;  // compressed copy of nodes (same indices); nullptr = traverse the full-width nodes (or qnodes8)
+    const QNode8 *qnodes8; // the 8-wide compressed tree (then nodes and qnodes are null)
+    float grid_lo[3], grid_step[3];  // the quantisation grid of qnodes: plane = grid_lo + (Q_BIAS + q) * grid_step
     const PrimRec<R> *prims;
     int32_t root_child;  // child word of the root (a leaf word when the scene has <= MAX_LEAF shapes)
     int32_t n_nodes;

@@ -47,6 +47,18 @@ namespace tk {
 #ifndef TQ_F64_WAVES
 #define TQ_F64_WAVES 4  // register cap of the f64 instances (waves per SIMD)
 #endif
+#ifndef TQ_W8_WAVES
+#define TQ_W8_WAVES 4       // register caps of the 8-wide instances (waves per SIMD): f32, f32 two-level, f64
+#endif
+#ifndef TQ_W8_INST_WAVES
+#define TQ_W8_INST_WAVES 4
+#endif
+#ifndef TQ_W8_F64_WAVES
+#define TQ_W8_F64_WAVES 4
+#endif
+#ifndef TQ_W8_LEVELS
+#define TQ_W8_LEVELS 19     // LDS stack levels of the 8-wide instances: 19 x 260 x 8 B = 39.5 KB per block = four blocks per CU
+#endif
 #ifndef TQ_G1_LEVELS
 // stack levels in LDS with one ray per lane: 15 x 260 entries x 8 B = 31 KB per block = the five blocks per CU the
 // registers allow (measured: 8 levels -13 %, 12 and 15 equal, 16 at four blocks -5 %)
@@ -191,14 +203,14 @@ template <class R> struct HookIo {  // the C-ABI trace hooks: AoS rays in, hit r
 // Geometry of a ray group: G lanes cooperate on one ray (G = 4: quad, one child slot per lane; G = 2: pair, two
 // slots per lane; G = 1: one ray per lane, four slots per lane).  More lanes per ray = better coalescing and less
 // divergence, fewer lanes per ray = fewer instructions per box test (the per-step overhead is shared by more boxes).
-template <int G> struct GroupGeom {
+template <int G, int W = 4> struct GroupGeom {
     static constexpr int LOG2 = G == 4 ? 2 : (G == 2 ? 1 : 0);
-    static constexpr int CPL = 4 / G;                    // child slots per lane
+    static constexpr int CPL = 4 / G;                    // child slots per lane (4-wide nodes)
     static constexpr int GROUPS = TQ_BLOCK / G;          // rays in flight per block
     static constexpr int PER_WAVE = 64 / G;
-    static constexpr int LEVELS = G == 4 ? 32 : (G == 2 ? TQ_PAIR_LEVELS : TQ_G1_LEVELS);  // stack levels in LDS
+    static constexpr int LEVELS = W == 8 ? TQ_W8_LEVELS : (G == 4 ? 32 : (G == 2 ? TQ_PAIR_LEVELS : TQ_G1_LEVELS));  // stack levels in LDS
     static constexpr int STRIDE = GROUPS + 4;            // entries per level (+4: 32 B skew between levels)
-    static constexpr int SPILL = MAX_STACK_ENTRIES + 4 - LEVELS;  // deeper levels in global memory (the builders cap the depth)
+    static constexpr int SPILL = (W == 8 ? MAX_STACK_ENTRIES_W8 : MAX_STACK_ENTRIES) + 4 - LEVELS;  // deeper levels in global memory (the builders cap the depth)
 };
 template <int G, class T> __device__ __forceinline__ T group_min(T v) {
     if (G >= 2) v = tk_fmin(v, dpp_f<QP_X1>(v));
@@ -216,12 +228,16 @@ template <int G> __device__ __forceinline__ int group_max_i(int v) {
 // the prototype's object space (t is the same number in both spaces), a return marker goes on the stack, traversal
 // continues at the prototype's root; when the marker is popped the ray gets its world-space form back.  A separate
 // instance of the kernel, so that one-level scenes pay nothing.
-template <class R, int G, bool ANY_HIT, bool COUNT, class Io, bool QN = false, bool INST = false>
-__global__ void __launch_bounds__(TQ_BLOCK, sizeof(R) == 8 ? (INST ? TQ_F64_WAVES - 1 : TQ_F64_WAVES) : (INST ? TQ_INST_WAVES : TQ_MIN_WAVES))  // f64, two-level: room for the wider state
+// W: node width of the compressed tree (QN): 4 = QNode4 (sc.qnodes), 8 = QNode8 (sc.qnodes8; one ray per lane only).
+template <class R, int G, bool ANY_HIT, bool COUNT, class Io, bool QN = false, bool INST = false, int W = 4>
+__global__ void __launch_bounds__(TQ_BLOCK, W == 8 ? (sizeof(R) == 8 ? TQ_W8_F64_WAVES : (INST ? TQ_W8_INST_WAVES : TQ_W8_WAVES))
+                                                   : (sizeof(R) == 8 ? (INST ? TQ_F64_WAVES - 1 : TQ_F64_WAVES) : (INST ? TQ_INST_WAVES : TQ_MIN_WAVES)))  // f64, two-level: room for the wider state
 k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32_t n_direct, int32_t *head,
               unsigned long long *counters, int counter_word, StackSpill spill) {
-    using GG = GroupGeom<G>;
+    using GG = GroupGeom<G, W>;
     constexpr int CPL = GG::CPL;
+    static_assert(W == 4 || (W == 8 && QN && G == 1), "8-wide nodes: compressed, one ray per lane");
+    constexpr uint32_t KEY_SLOT_MASK = W == 8 ? 7u : 3u;  // low bits of an order key hold the slot
     __shared__ tq_entry s_stack[GG::LEVELS * GG::STRIDE];
     typedef __attribute__((address_space(3))) tq_entry lds_entry;
     const int lane = threadIdx.x & 63;
@@ -234,7 +250,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
     if (blockIdx.x == 0 && threadIdx.x == 0 && counter_word >= 0)
         atomicAdd(&counters[counter_word], (unsigned long long)n);
     static_assert(!QN || G <= 2, "compressed nodes: one ray per lane (production) and the pair kernel");
-    const char *const node_base = QN ? (const char *)sc.qnodes : (const char *)sc.nodes;
+    const char *const node_base = QN ? (W == 8 ? (const char *)sc.qnodes8 : (const char *)sc.qnodes) : (const char *)sc.nodes;
     const char *const prim_base = (const char *)sc.prims;
 
     // wave-local pool of queue indices [pool_next, pool_end), refilled 64 at a time
@@ -292,7 +308,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                 continue;
             }
             if (ANY_HIT) return false;  // the limit of a shadow ray never shrinks: nothing to cull
-            const float key = __uint_as_float((uint32_t)(e >> 32) & ~3u);
+            const float key = __uint_as_float((uint32_t)(e >> 32) & ~KEY_SLOT_MASK);
             if ((R)key <= tbest) return false;
         }
     };
@@ -418,6 +434,54 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                 const int nw = __builtin_popcountll(m_leaf), ni = __builtin_popcountll(tq_ballot(cur == CHILD_EMPTY));
                 if (lane == 0) cnt_wnode++, cnt_wait += (uint32_t)(nw >> GG::LOG2), cnt_idle += (uint32_t)(ni >> GG::LOG2);
             }
+            if constexpr (W == 8) {
+              if (at_node) {
+                // ---- 8-wide step.  The lane loads its ray's eight 16-byte slots in VISITING order: the slot of rank k
+                // sits at byte (k << 4) ^ oct16 of the node's line (slot = rank ^ octant: front to back as far as one
+                // permutation per octant can tell).  Closest hit: the nearest hit child (minimum of the eight keys =
+                // entry distance bits | rank) is visited next, the others go on the stack far rank first, each with
+                // its key for the pop-time culling — no ranking of eight distances.  Shadow rays: key = rank.
+                if (COUNT) cnt_nodes++;
+                const uint32_t off = ((uint32_t)cur * (uint32_t)sizeof(QNode8)) ^ qr.oct16;
+                uint4 c[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) c[k] = *(const uint4 *)(node_base + (off ^ (uint32_t)(k << 4)));
+                uint32_t key[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    float tn;
+                    const bool ok = qbox_test(qr, c[k].x, c[k].y, c[k].z, (int32_t)c[k].w, lim_lo(), lim_hi(), tn);
+                    if (ANY_HIT) key[k] = ok ? (uint32_t)k : TQ_KEY_INVALID;
+                    else key[k] = ok ? ((__float_as_uint(TQ_PRESCALE ? tn : tn * Const<float>::BOX_SHRINK) & ~7u) | (uint32_t)k) : TQ_KEY_INVALID;
+                }
+                const uint32_t kmin = min(min(min(key[0], key[1]), min(key[2], key[3])), min(min(key[4], key[5]), min(key[6], key[7])));
+                if (kmin != TQ_KEY_INVALID) {
+                    int32_t cand = CHILD_EMPTY;
+                    int cnt = 0;
+                    if (sp + 7 <= GG::LEVELS) {  // all of this step's entries land in LDS: no per-entry check
+#pragma unroll
+                        for (int k = 7; k >= 0; k--) {
+                            if (key[k] == kmin) cand = (int32_t)c[k].w;
+                            const bool push = key[k] != TQ_KEY_INVALID && key[k] != kmin;  // (valid keys are distinct)
+                            if (push) *lds_level(sp + cnt) = ((tq_entry)key[k] << 32) | (tq_entry)c[k].w;
+                            cnt += push ? 1 : 0;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 7; k >= 0; k--) {
+                            if (key[k] == kmin) cand = (int32_t)c[k].w;
+                            const bool push = key[k] != TQ_KEY_INVALID && key[k] != kmin;
+                            if (push) push_entry(sp + cnt, ((tq_entry)key[k] << 32) | (tq_entry)c[k].w);
+                            cnt += push ? 1 : 0;
+                        }
+                    }
+                    sp += cnt;
+                    cur = cand;
+                } else if (advance()) {
+                    finish();
+                }
+              }
+            } else
             if (at_node) {
                 if (COUNT && gl == 0) cnt_nodes++;
                 uint32_t key[CPL];
@@ -431,7 +495,7 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                         const uint4 c = *(const uint4 *)(node_base + off + j * (uint32_t)sizeof(QChild));
                         float tn;
                         const bool ok = qbox_test(qr, c.x, c.y, c.z, (int32_t)c.w, lim_lo(), lim_hi(), tn);
-                        key[j] = ok ? ((__float_as_uint(tn * Const<float>::BOX_SHRINK) & ~3u) | (uint32_t)(3 - (gl * CPL + j)))
+                        key[j] = ok ? ((__float_as_uint(TQ_PRESCALE ? tn : tn * Const<float>::BOX_SHRINK) & ~3u) | (uint32_t)(3 - (gl * CPL + j)))
                                     : TQ_KEY_INVALID;
                         child[j] = (int32_t)c.w;
                     }

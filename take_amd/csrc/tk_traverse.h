@@ -115,25 +115,56 @@ TK_HD bool box_test(const NodeChild<R> &c, Vec3<R> o, R idx, R idy, R idz, R tmi
     return (tn * Const<R>::BOX_SHRINK <= tf * Const<R>::BOX_GROW) && (c.child != CHILD_EMPTY);
 }
 
-// ---- compressed nodes (QNode4, f32 only).  The ray is moved into grid space once (QRay) instead of decoding planes:
-//   t(q) = (grid_lo + q step - o) / d = A + q B,   A = (grid_lo - o) * inv_d,   B = inv_d * step
-// Rounding: A carries two roundings, i.e. the plane looks displaced by <= |grid_lo - o| 2^-23.  When the origin is
-// within 4 grid extents of grid_lo that is <= extent 2^-21, which the builder adds to every child box before
-// snapping it outwards to the grid (tk_bvh.h: quantise_nodes; 0.03 cell); farther away it is a relative error of
-// the distance, which together with inv_d, B and the final fma rounding stays below 2 ulp, inside BOX_SHRINK /
-// BOX_GROW (3 ulp) like the full-width test.
+// ---- compressed nodes (QNode4).  The ray is moved into grid space once (QRay) instead of decoding planes:
+//   t(q) = (grid_lo + (Q_BIAS + q) step - o) / d = A + F(q) B,   F(q) = 4 (Q_BIAS + q),   A = (grid_lo - o) * inv_d,
+//   B = inv_d * step / 4.
+// F(q) is the float with the bits 0x48000000 | q << 8 (q < 2^15: exponent 2^17, q in mantissa bits 8..22) — one byte
+// permute of the slot word, no integer-to-float conversion — and the fma rounds F B + A once.
+// Rounding (X = (Q_BIAS + q) step in [1, 2] grid extents, Y = grid_lo - o): the computed numerator is
+// X (1 + e4) + Y (1 + e2 + e3), |e| <= 2^-24, i.e. the plane looks displaced by <= 2^-24 (X + 2 |Y|).  With the origin
+// inside the scene box (|Y| <= 2 extents) that is <= 6 2^-24 = 0.75 2^-21 extents, which the builder adds to every
+// child box before snapping it outwards to the grid (tk_bvh.h: make_qgrid, delta = 2^-20 extents); farther away it is
+// 3 2^-24 X (inside delta) plus a relative error of 2 2^-24 of the distance, which together with inv_d and the final
+// fma rounding (2 more) stays inside BOX_SHRINK / BOX_GROW (6.7 2^-24 each) like the full-width test.
+#ifndef TQ_PRESCALE
+#define TQ_PRESCALE 0  // 1: the conservative margins are folded into the ray's grid-space constants (experiment)
+#endif
 struct QRay {
     float ax, ay, az, bx, by, bz;
-    // per axis 0 or 16: rotating a slot's (lo | hi << 16) word by this puts the plane the ray meets first into the low
-    // half — the entry and exit distances then come out of the fma directly, without a min / max per axis and box
-    uint32_t rx, ry, rz;
+#if TQ_PRESCALE
+    // the far planes' constants: (a, b) * BOX_GROW, while ax.. bz hold (a, b) * BOX_SHRINK — the margins of the slab
+    // test cost no instruction.  Scaling the two terms of F b + a separately adds 2^-24 (X + |Y|) to the plane's
+    // displacement (<= 0.5 2^-21 extents inside the scene: still within delta) and 2^-24 to the relative error.
+    float axf, ayf, azf, bxf, byf, bzf;
+#endif
+    // per axis the v_perm_b32 selector that turns a slot word (lo | hi << 16) into F of the plane the ray meets FIRST
+    // (lo for a positive slope, hi for a negative one); the other plane's selector is this one ^ QSEL_FLIP.  The entry
+    // and exit distances come out of the fma directly, without a min / max per axis and box.
+    uint32_t sx, sy, sz;
+    uint32_t oct16;  // 8-wide nodes: (octant of the direction: bit a set = negative along axis a) << 4 = the byte offset
+                     // that turns a visiting rank into a slot (slot = rank ^ octant, tk_scene.h: QNode8)
 };
-TK_HD void qray_rotations(QRay &f) { f.rx = f.bx < 0.0f ? 16u : 0u, f.ry = f.by < 0.0f ? 16u : 0u, f.rz = f.bz < 0.0f ? 16u : 0u; }
+constexpr uint32_t QSEL_LO = 0x0005040Cu;    // bytes (0x00, w.b0, w.b1, K.b0): the low half of the slot word
+constexpr uint32_t QSEL_HI = 0x0007060Cu;    // bytes (0x00, w.b2, w.b3, K.b0): the high half
+constexpr uint32_t QSEL_FLIP = QSEL_LO ^ QSEL_HI;
+constexpr uint32_t QPERM_K = 0x48484848u;    // exponent byte of 2^17
+TK_HD void qray_selectors(QRay &f) {
+    f.sx = f.bx < 0.0f ? QSEL_HI : QSEL_LO, f.sy = f.by < 0.0f ? QSEL_HI : QSEL_LO, f.sz = f.bz < 0.0f ? QSEL_HI : QSEL_LO;
+    f.oct16 = (f.bx < 0.0f ? 16u : 0u) | (f.by < 0.0f ? 32u : 0u) | (f.bz < 0.0f ? 64u : 0u);
+}
+TK_HD void qray_margins(QRay &f) {
+#if TQ_PRESCALE
+    const float G = Const<float>::BOX_GROW, S = Const<float>::BOX_SHRINK;
+    f.axf = f.ax * G, f.ayf = f.ay * G, f.azf = f.az * G, f.bxf = f.bx * G, f.byf = f.by * G, f.bzf = f.bz * G;
+    f.ax *= S, f.ay *= S, f.az *= S, f.bx *= S, f.by *= S, f.bz *= S;
+#endif
+}
 TK_HD QRay qray_make(const float *grid_lo, const float *grid_step, Vec3<float> o, float idx, float idy, float idz) {
     QRay f;
     f.ax = (grid_lo[0] - o.x) * idx, f.ay = (grid_lo[1] - o.y) * idy, f.az = (grid_lo[2] - o.z) * idz;
-    f.bx = idx * grid_step[0], f.by = idy * grid_step[1], f.bz = idz * grid_step[2];
-    qray_rotations(f);
+    f.bx = idx * grid_step[0] * 0.25f, f.by = idy * grid_step[1] * 0.25f, f.bz = idz * grid_step[2] * 0.25f;
+    qray_selectors(f);
+    qray_margins(f);
     return f;
 }
 // f64 rays traverse the same compressed nodes with the same f32 slab test: A and B are formed in double and rounded
@@ -143,37 +174,55 @@ TK_HD QRay qray_make(const float *grid_lo, const float *grid_step, Vec3<double> 
     QRay f;
     f.ax = (float)(((double)grid_lo[0] - o.x) * idx), f.ay = (float)(((double)grid_lo[1] - o.y) * idy),
     f.az = (float)(((double)grid_lo[2] - o.z) * idz);
-    f.bx = (float)(idx * (double)grid_step[0]), f.by = (float)(idy * (double)grid_step[1]), f.bz = (float)(idz * (double)grid_step[2]);
-    qray_rotations(f);
+    f.bx = (float)(idx * (double)grid_step[0] * 0.25), f.by = (float)(idy * (double)grid_step[1] * 0.25), f.bz = (float)(idz * (double)grid_step[2] * 0.25);
+    qray_selectors(f);
+    qray_margins(f);
     return f;
 }
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef float tk_f2 __attribute__((ext_vector_type(2)));
-// both planes of one axis in one packed fma (v_pk_fma_f32): same value per element as the scalar form below
-__device__ __forceinline__ void qplanes(uint32_t w, float b, float a, float &t0, float &t1) {
-    const tk_f2 q = {(float)(w & 0xffffu), (float)(w >> 16)};
-    const tk_f2 t = __builtin_elementwise_fma(q, (tk_f2){b, b}, (tk_f2){a, a});
+// both planes of one axis: two byte permutes and one packed fma (v_pk_fma_f32); same value per element as the scalar
+// form below
+__device__ __forceinline__ void qplanes(uint32_t w, uint32_t sel, float b0, float a0, float b1, float a1, float &t0, float &t1) {
+    const tk_f2 q = {__uint_as_float(__builtin_amdgcn_perm(w, QPERM_K, sel)), __uint_as_float(__builtin_amdgcn_perm(w, QPERM_K, sel ^ QSEL_FLIP))};
+    const tk_f2 t = __builtin_elementwise_fma(q, (tk_f2){b0, b1}, (tk_f2){a0, a1});
     t0 = t.x, t1 = t.y;
 }
-__device__ __forceinline__ uint32_t qrot(uint32_t w, uint32_t r) { return __builtin_amdgcn_alignbit(w, w, r); }
 #else
-inline uint32_t qrot(uint32_t w, uint32_t r) { return r ? ((w >> 16) | (w << 16)) : w; }
-inline void qplanes(uint32_t w, float b, float a, float &t0, float &t1) {
-    t0 = __builtin_fmaf((float)(w & 0xffffu), b, a);
-    t1 = __builtin_fmaf((float)(w >> 16), b, a);
+inline float qplane_float(uint32_t q) {
+    union {
+        uint32_t u;
+        float f;
+    } c;
+    c.u = 0x48000000u | (q << 8);
+    return c.f;
+}
+inline void qplanes(uint32_t w, uint32_t sel, float b0, float a0, float b1, float a1, float &t0, float &t1) {
+    const uint32_t lo = w & 0xffffu, hi = w >> 16;
+    t0 = __builtin_fmaf(qplane_float(sel == QSEL_LO ? lo : hi), b0, a0);
+    t1 = __builtin_fmaf(qplane_float(sel == QSEL_LO ? hi : lo), b1, a1);
 }
 #endif
 // conservative slab test of one compressed child slot
 TK_HD bool qbox_test(const QRay &f, uint32_t qx, uint32_t qy, uint32_t qz, int32_t child, float tmin, float tbest, float &tn) {
-    // near / far plane per axis by rotation (QRay): the same two values min / max would pick — the fma is monotone in
+    // near / far plane per axis by selector (QRay): the same two values min / max would pick — the fma is monotone in
     // the plane coordinate, increasing for a positive slope and decreasing for a negative one
     float nx, fx, ny, fy, nz, fz;
-    qplanes(qrot(qx, f.rx), f.bx, f.ax, nx, fx);
-    qplanes(qrot(qy, f.ry), f.by, f.ay, ny, fy);
-    qplanes(qrot(qz, f.rz), f.bz, f.az, nz, fz);
+#if TQ_PRESCALE
+    qplanes(qx, f.sx, f.bx, f.ax, f.bxf, f.axf, nx, fx);
+    qplanes(qy, f.sy, f.by, f.ay, f.byf, f.ayf, ny, fy);
+    qplanes(qz, f.sz, f.bz, f.az, f.bzf, f.azf, nz, fz);
+    tn = tk_fmax(tk_fmax(nx, ny), tk_fmax(nz, tmin));  // (already shrunk: tn is the culling key as it stands)
+    const float tf = tk_fmin(tk_fmin(fx, fy), tk_fmin(fz, tbest));
+    return (tn <= tf) && (child != CHILD_EMPTY);
+#else
+    qplanes(qx, f.sx, f.bx, f.ax, f.bx, f.ax, nx, fx);
+    qplanes(qy, f.sy, f.by, f.ay, f.by, f.ay, ny, fy);
+    qplanes(qz, f.sz, f.bz, f.az, f.bz, f.az, nz, fz);
     tn = tk_fmax(tk_fmax(nx, ny), tk_fmax(nz, tmin));
     const float tf = tk_fmin(tk_fmin(fx, fy), tk_fmin(fz, tbest));
     return (tn * Const<float>::BOX_SHRINK <= tf * Const<float>::BOX_GROW) && (child != CHILD_EMPTY);
+#endif
 }
 
 struct TravCount {
@@ -192,15 +241,43 @@ TK_HD void traverse(const DeviceScene<R> &sc, const RayT<R> &ray, Stack &stack, 
     const R idx = safe_inv(ray.d.x), idy = safe_inv(ray.d.y), idz = safe_inv(ray.d.z);
     R tbest = ray.tmax;
     QRay qr{};
-    if (sc.qnodes) qr = qray_make(sc.grid_lo, sc.grid_step, ray.o, idx, idy, idz);
+    const bool qn8 = sc.qnodes8 != nullptr;
+    const bool qn = sc.qnodes != nullptr || qn8;
+    if (qn) qr = qray_make(sc.grid_lo, sc.grid_step, ray.o, idx, idy, idz);
     const float tmin_f = stack_key(ray.tmin);  // largest float <= tmin
-    const bool qn = sc.qnodes != nullptr;
     // conservative float image of an entry distance (the stack's culling key): the compressed test computes in f32
     // whatever R is, so its margin is the f32 one
-    auto cull_key = [&](R k) -> float { return qn ? (float)k * Const<float>::BOX_SHRINK : stack_key(k * Const<R>::BOX_SHRINK); };
+    auto cull_key = [&](R k) -> float { return qn ? (TQ_PRESCALE ? (float)k : (float)k * Const<float>::BOX_SHRINK) : stack_key(k * Const<R>::BOX_SHRINK); };
+    // 8-wide nodes: the slots are visited in the order slot ^ octant (tk_scene.h: QNode8)
+    const int oct = (int)(qr.oct16 >> 4);
     int sp = 0;
     int32_t cur = sc.root_child;
     for (;;) {
+        if (cur >= 0 && qn8) {
+            // the order of the trace kernel's 8-wide step: the nearest hit child is visited next (closest hit) / the
+            // first one in octant order (any hit), the others are pushed far to near in octant order
+            if (COUNT) tc.nodes++;
+            const QNode8 &n = sc.qnodes8[cur];
+            const float tbest_f = float_above(tbest);
+            R key[8];
+            int32_t ch[8];
+            int nearest = -1;
+            for (int k = 0; k < 8; k++) {
+                const QChild &c = n.c[k ^ oct];
+                float tn;
+                const bool ok = qbox_test(qr, c.q[0], c.q[1], c.q[2], c.child, tmin_f, tbest_f, tn);
+                key[k] = ok ? (R)tn : Const<R>::inf();
+                ch[k] = c.child;
+                if (ok && (nearest < 0 || (!ANY_HIT && key[k] < key[nearest]))) nearest = k;
+            }
+            for (int k = 7; k >= 0; k--)
+                if (k != nearest && key[k] < Const<R>::inf()) stack.push(sp++, ch[k], cull_key(key[k]));
+            if (nearest >= 0) {
+                cur = ch[nearest];
+                continue;
+            }
+            goto pop_next;
+        }
         if (cur >= 0) {
             if (COUNT) tc.nodes++;
             R key[4];

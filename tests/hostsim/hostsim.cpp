@@ -168,6 +168,31 @@ template <class R> int trace_t(const TakeSceneDesc &desc, const void *rays_v, in
     }
     return TAKE_OK;
 }
+// Compressed nodes of the f32 scene against the full-width ones they were made from, in exact (double) arithmetic.
+// out[0] = child slots checked, out[1] = slots whose decoded box does NOT contain the true box widened by the
+// builder's slack (must be 0), out[2] = child words that differ (must be 0), out[3] = 1e6 * surface-area inflation,
+// out[4] = 1 if the scene uses compressed nodes, out[5] = node width (4 or 8), out[6] = 8-wide only: children whose
+// centre lies on the wrong side of the node's centre on some axis for their slot (diagnostic, not an error)
+template <int W>
+static void check_qnodes_w(const HostScene<float> &hs, const std::vector<NodeW<float, W>> &nodes, const std::vector<QNodeW<W>> &qnodes, int64_t *out) {
+    for (size_t n = 0; n < nodes.size(); n++)
+        for (int i = 0; i < W; i++) {
+            const NodeChild<float> &c = nodes[n].c[i];
+            const QChild &q = qnodes[n].c[i];
+            if (c.child != q.child) out[2]++;
+            if (c.child == CHILD_EMPTY) continue;
+            out[0]++;
+            bool ok = true;
+            for (int a = 0; a < 3; a++) {
+                const double lo = (double)hs.grid_lo[a] + (double)(Q_BIAS + (q.q[a] & 0xffffu)) * (double)hs.grid_step[a];
+                const double hi = (double)hs.grid_lo[a] + (double)(Q_BIAS + (q.q[a] >> 16)) * (double)hs.grid_step[a];
+                const double slack = (double)Q_MAX * (double)hs.grid_step[a] * 0x1p-20;
+                if (!(lo <= (double)c.bmin[a] - slack && hi >= (double)c.bmax[a] + slack)) ok = false;
+                if ((q.q[a] & 0xffffu) > (q.q[a] >> 16) || (q.q[a] >> 16) > (uint32_t)Q_MAX) ok = false;
+            }
+            if (!ok) out[1]++;
+        }
+}
 }  // namespace
 
 extern "C" {
@@ -177,10 +202,6 @@ int hostsim_render(const TakeSceneDesc *desc, int precision, const TakeRenderOpt
     return precision == TAKE_PRECISION_F64 ? render_t<double>(*desc, *opts, out, stats)
                                            : render_t<float>(*desc, *opts, out, stats);
 }
-// Compressed nodes of the f32 scene against the full-width ones they were made from, in exact (double) arithmetic.
-// out[0] = child slots checked, out[1] = slots whose decoded box does NOT contain the true box widened by the
-// builder's slack (must be 0), out[2] = child words that differ (must be 0), out[3] = 1e6 * surface-area inflation,
-// out[4] = 1 if the scene uses compressed nodes.
 int hostsim_check_qnodes(const TakeSceneDesc *desc, int64_t *out) {
     HostScene<float> hs;
     std::string err = prepare_scene<float>(*desc, 0, 2, hs);
@@ -188,27 +209,12 @@ int hostsim_check_qnodes(const TakeSceneDesc *desc, int64_t *out) {
         g_err = err;
         return -1;
     }
-    out[0] = out[1] = out[2] = 0;
+    out[0] = out[1] = out[2] = out[6] = 0;
     out[3] = (int64_t)(hs.q_inflation * 1e6);
-    out[4] = hs.qnodes.empty() ? 0 : 1;
-    if (hs.qnodes.empty()) return 0;
-    for (size_t n = 0; n < hs.nodes.size(); n++)
-        for (int i = 0; i < 4; i++) {
-            const NodeChild<float> &c = hs.nodes[n].c[i];
-            const QChild &q = hs.qnodes[n].c[i];
-            if (c.child != q.child) out[2]++;
-            if (c.child == CHILD_EMPTY) continue;
-            out[0]++;
-            bool ok = true;
-            for (int a = 0; a < 3; a++) {
-                const double lo = (double)hs.grid_lo[a] + (double)(q.q[a] & 0xffffu) * (double)hs.grid_step[a];
-                const double hi = (double)hs.grid_lo[a] + (double)(q.q[a] >> 16) * (double)hs.grid_step[a];
-                const double slack = 65535.0 * (double)hs.grid_step[a] * 0x1p-21;
-                if (!(lo <= (double)c.bmin[a] - slack && hi >= (double)c.bmax[a] + slack)) ok = false;
-                if ((q.q[a] & 0xffffu) > (q.q[a] >> 16)) ok = false;
-            }
-            if (!ok) out[1]++;
-        }
+    out[4] = hs.qnodes.empty() && hs.qnodes8.empty() ? 0 : 1;
+    out[5] = hs.node_width;
+    if (!hs.qnodes8.empty()) check_qnodes_w<8>(hs, hs.nodes8, hs.qnodes8, out);
+    else if (!hs.qnodes.empty()) check_qnodes_w<4>(hs, hs.nodes, hs.qnodes, out);
     return 0;
 }
 // rays: n x 8 Real laid out as TakeRayF/TakeRayD; hits: n x 4 Real (shape id as Real, t, u, v)

@@ -52,13 +52,20 @@ def test_1m_compressed_nodes_in_use(soup1m):
     soup1m.render(spp=1, max_depth=2, seed=0)
     c = soup1m.counters()
     soup1m.set_instrumentation(False, False)
-    assert c["node_bytes"] == 64  # the 16-bit grid is fine enough for 1M triangles: no fall-back to 128-byte nodes
+    assert c["node_bytes"] == 64  # the 15-bit grid is fine enough for 1M triangles: no fall-back to 128-byte nodes
     assert c["samples"] == 1920 * 1080
 
 
-def test_1m_node_format_does_not_change_results(soup1m):
-    wide = _scene(1_000_000, 1920, 1080, "wide")
+@pytest.mark.parametrize("fmt", ["wide", "q8"])
+def test_1m_node_format_does_not_change_results(soup1m, fmt):
+    """full-width 4-wide nodes and the 8-wide compressed tree (TAKE_HIP_NODES=q8: another tree shape, octant-ordered
+    slots, its own kernel instances) against the default 4-wide compressed tree: bit-identical images and hit tables"""
+    wide = _scene(1_000_000, 1920, 1080, fmt)
     try:
+        wide.set_instrumentation(timing=False, counting=True)
+        wide.render(spp=1, max_depth=2, seed=0)
+        assert wide.counters()["node_bytes"] == 128  # (both alternatives have 128-byte nodes)
+        wide.set_instrumentation(False, False)
         a = soup1m.render(spp=1, max_depth=50, seed=5)
         b = wide.render(spp=1, max_depth=50, seed=5)
         assert np.array_equal(a, b)

@@ -31,6 +31,28 @@ def test_wide_bvh_closest_hit_equals_exhaustive_search(name, precision):
     assert np.array_equal(got[hit, 1:4], want[hit, 1:4])  # t, u, v bit for bit
 
 
+@pytest.mark.parametrize("precision", [1, 0])
+def test_eight_wide_tree_equals_exhaustive_search(precision, monkeypatch):
+    """TAKE_HIP_NODES=q8: the 8-wide compressed tree (octant-ordered slots, nearest child first, the others in
+    octant order) finds the same closest hits and the same occlusion as the exhaustive search — on a soup deep enough
+    for several 8-wide levels and on two golden scenes"""
+    monkeypatch.setenv("TAKE_HIP_NODES", "q8")
+    for sd in (scenes.soup_scene(20_000, 32, 32, spp=1), golden_scene("mats"), golden_scene("soup1k")):
+        rays = random_rays(2000, 9, bounded_fraction=0.5, tmin=1e-7)
+        if precision == 0:
+            rays = rays.astype(np.float32).astype(np.float64)
+        osc = oracle.OracleScene(sd, precision=precision)
+        want = osc.isect_brute(rays)
+        osc.close()
+        got = hostsim_trace(sd, precision, rays).astype(np.float64)
+        assert (got[:, 0] == want[:, 0]).all()
+        hit = want[:, 0] >= 0
+        assert hit.sum() > 500
+        assert np.array_equal(got[hit, 1:4], want[hit, 1:4])
+        occ = hostsim_trace(sd, precision, rays, any_hit=True)[:, 0] >= 0
+        assert np.array_equal(occ, hit)
+
+
 @pytest.mark.parametrize("name", GOLDEN_SCENES)
 def test_any_hit_equals_closest_hit_boolean(name):
     sd = golden_scene(name)
@@ -118,40 +140,58 @@ def test_emissive_mesh_without_normals_is_rejected():
         hostsim_render(sd, 0, 1, 1)
 
 
-# ------------------------------------------------------------------ compressed BVH nodes (16-bit scene grid)
-def _check_qnodes(sd):
+# ------------------------------------------------------------------ compressed BVH nodes (15-bit scene grid)
+NODE_FORMATS = [("", 4), ("q8", 8)]  # TAKE_HIP_NODES value -> node width (default: the 4-wide tree)
+
+
+def _check_qnodes(sd, fmt=""):
     import ctypes as C
+    import os
 
     from helpers import hostsim
 
-    out = (C.c_int64 * 5)()
+    out = (C.c_int64 * 8)()
     desc, keep = sd.to_desc()
-    rc = hostsim().hostsim_check_qnodes(C.byref(desc), out)
+    old = os.environ.get("TAKE_HIP_NODES")
+    try:
+        if fmt:
+            os.environ["TAKE_HIP_NODES"] = fmt
+        else:
+            os.environ.pop("TAKE_HIP_NODES", None)
+        rc = hostsim().hostsim_check_qnodes(C.byref(desc), out)
+    finally:
+        if old is None:
+            os.environ.pop("TAKE_HIP_NODES", None)
+        else:
+            os.environ["TAKE_HIP_NODES"] = old
     assert rc == 0, hostsim().hostsim_last_error()
-    return list(out)
+    return list(out)[:6]
 
 
+@pytest.mark.parametrize("fmt,width", NODE_FORMATS)
 @pytest.mark.parametrize("name", GOLDEN_SCENES)
-def test_compressed_nodes_contain_the_true_boxes(name):
+def test_compressed_nodes_contain_the_true_boxes(name, fmt, width):
     """every compressed child box (exact arithmetic) contains the true box plus the builder's slack, child words
-    are unchanged, and the f32 golden scenes all use the compressed format"""
-    slots, bad, diff, infl, in_use = _check_qnodes(golden_scene(name))
+    are unchanged, and the f32 golden scenes all use the compressed format — for the 4-wide tree (default) and the
+    8-wide one"""
+    slots, bad, diff, infl, in_use, w = _check_qnodes(golden_scene(name), fmt)
     assert bad == 0 and diff == 0
     if slots:
-        assert in_use == 1 and 1.0 <= infl / 1e6 < 1.10
+        assert in_use == 1 and 1.0 <= infl / 1e6 < 1.10 and w == width
 
 
-def test_compressed_nodes_on_a_large_soup_and_scale_mixing_fallback():
-    slots, bad, diff, infl, in_use = _check_qnodes(scenes.soup_scene(200_000, 64, 64, spp=1))
-    assert slots > 100_000 and bad == 0 and diff == 0 and in_use == 1
-    assert infl / 1e6 < 1.02  # a 16-bit cell is far below a soup triangle
-    # a scene mixing scales by 1e6 (tiny triangles next to a huge one): the 16-bit grid would inflate the small
-    # boxes many times over, the builder must keep the full-width nodes
+@pytest.mark.parametrize("fmt,width", NODE_FORMATS)
+def test_compressed_nodes_on_a_large_soup_and_scale_mixing_fallback(fmt, width):
+    slots, bad, diff, infl, in_use, w = _check_qnodes(scenes.soup_scene(200_000, 64, 64, spp=1), fmt)
+    assert slots > 100_000 and bad == 0 and diff == 0 and in_use == 1 and w == width
+    assert infl / 1e6 < 1.02  # a 15-bit cell is far below a soup triangle
+    # a scene mixing scales by 1e6 (tiny triangles next to a huge one): the 15-bit grid would inflate the small
+    # boxes many times over, the builder must keep the full-width (4-wide) nodes
     rng = np.random.default_rng(3)
     sd = scenes.soup_scene(64, 32, 32, spp=1)
     tiny = (rng.uniform(-1, 1, (2000, 1, 3)) * 1e-3 + rng.uniform(-1, 1, (2000, 3, 3)) * 1e-6).astype(np.float64)
     sd.add_mesh(tiny.reshape(-1, 3), np.arange(6000, dtype=np.int32).reshape(-1, 3), 0)
     big = np.array([[-1e3, -1e3, -5.0], [1e3, -1e3, -5.0], [0.0, 1e3, -5.0]])
     sd.add_mesh(big, np.array([[0, 1, 2]], np.int32), 0)
-    slots, bad, diff, infl, in_use = _check_qnodes(sd)
-    assert in_use == 0 and infl / 1e6 > 1.10
+    slots, bad, diff, infl, in_use, w = _check_qnodes(sd, fmt)
+    assert in_use == 0 and infl / 1e6 > 1.10 and w == 4
