@@ -234,7 +234,11 @@ typedef struct TakeScene TakeScene; /* opaque */
 
 /* ray / hit records of the trace hooks (test + traversal-only benchmark surface;
  * counterpart of scene_intersect / scene_occluded, src/scene.cpp:25-64).
- * Real-typed views: f32 scenes take/return the float fields, f64 scenes the doubles. */
+ * Real-typed views: f32 scenes take/return the float fields, f64 scenes the doubles.
+ * Contract of every trace hook: tmin >= 0 (the traversal orders entry distances through their bit patterns, which
+ * needs non-negative values).  The host entry points (take_hip_trace_closest / _any) refuse a ray with tmin < 0 or
+ * NaN with TAKE_E_INVALID; the *_device entry points, which cannot look at device-resident rays, start such a ray —
+ * and one with tmin = -0.0 — at tmin = 0. */
 typedef struct TakeRayF {
     float org[3], tmin, dir[3], tmax;
 } TakeRayF;

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -39,10 +40,13 @@ int fail(int code, const std::string &msg) {
 // Fault injection for the allocation-failure tests (tests/test_gpu_robustness.py): TAKE_HIP_FAIL_ALLOC=<k> makes the
 // k-th device allocation after the variable was (re)set fail with hipErrorOutOfMemory.  A real out-of-memory cannot
 // be provoked reliably from a test: the driver over-commits, a 300 GB request on a 288 GB device succeeded.
+// (allocations happen on several host threads at once — one per shard of a scene group — hence the lock)
 inline bool inject_alloc_failure() {
+    static std::mutex mu;
     static std::string seen;
     static long calls = 0;
     const char *e = std::getenv("TAKE_HIP_FAIL_ALLOC");
+    std::lock_guard<std::mutex> lock(mu);
     if (!e || !*e) {
         seen.clear();
         return false;
@@ -154,6 +158,7 @@ struct TakeScene {
     int precision = TAKE_PRECISION_F32;
     int device = 0;
     int num_cus = 256;
+    int mem_share = 1;  // scenes of one group on this device: each sizes its path-state batch for 1/mem_share of the free HBM
     int instrumentation = 0;
     SceneT<float> f;
     SceneT<double> d;
@@ -683,7 +688,8 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
         const int64_t per_path = (int64_t)PATH_REC * (int64_t)sizeof(R) + 4 * (int64_t)sizeof(int32_t);
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const int64_t have = (int64_t)sc.capacity * per_path;  // already allocated by an earlier render
-            target = std::min<int64_t>(target, std::max<int64_t>((int64_t)1 << 20, ((int64_t)free_b + have) / 2 / per_path));
+            // (shards of a scene group that share a device size their batches concurrently: each takes its share)
+            target = std::min<int64_t>(target, std::max<int64_t>((int64_t)1 << 20, ((int64_t)free_b / std::max(1, ts->mem_share) + have) / 2 / per_path));
         }
     }
     int spb = o.samples_per_batch > 0 ? o.samples_per_batch : (int)std::max<int64_t>(1, target / npix);
@@ -1190,7 +1196,7 @@ template <class T> int peer_copy(DevBuf<T> &dst, int dst_dev, const DevBuf<T> &s
         return fail(TAKE_E_DEVICE, "hipMemcpyPeer of a scene array failed");
     return TAKE_OK;
 }
-template <class R> int replicate_t(const SceneT<R> &a, int a_dev, SceneT<R> &b, int b_dev) {
+template <class R> int replicate_t(const SceneT<R> &a, int a_dev, int a_cus, SceneT<R> &b, int b_dev, int b_cus) {
     int rc = TAKE_OK;
 #define TK_COPY(member) if (!rc) rc = peer_copy(b.member, b_dev, a.member, a_dev)
     TK_COPY(nodes); TK_COPY(qnodes); TK_COPY(qnodes8); TK_COPY(prims); TK_COPY(meshes); TK_COPY(face_idx); TK_COPY(normals); TK_COPY(uvs);
@@ -1214,8 +1220,14 @@ template <class R> int replicate_t(const SceneT<R> &a, int a_dev, SceneT<R> &b, 
     d.materials = b.materials.p, d.images = b.images.p, d.lights = b.lights.p, d.light_pmf = b.light_pmf.p, d.light_cdf = b.light_cdf.p;
     d.inst_trace = b.inst_trace.p, d.inst_shade = b.inst_shade.p;
     d.env.marginal = b.env_marginal.p, d.env.conditional = b.env_conditional.p, d.env.guide_m = b.env_guide_m.p, d.env.guide_c = b.env_guide_c.p;
-    b.group = a.group, b.built_on_device = a.built_on_device, b.trace_grid = a.trace_grid, b.spill_stride = a.spill_stride;
-    if (b.qwords.alloc(a.qwords.n) != hipSuccess || b.counters.alloc(a.counters.n) != hipSuccess || b.spill.alloc(a.spill.n) != hipSuccess)
+    // the persistent trace grid of THIS device: blocks per CU are a property of the kernels (the same code object on
+    // every device), the CU count is the replica device's own
+    const int per_cu = std::max(1, a.trace_grid / std::max(1, a_cus));
+    const int64_t groups_per_block = a.trace_grid > 0 ? a.spill_stride / a.trace_grid : 0;
+    const int64_t spill_levels = a.spill_stride > 0 ? (int64_t)a.spill.n / a.spill_stride : 0;
+    b.group = a.group, b.built_on_device = a.built_on_device, b.trace_grid = per_cu * b_cus, b.spill_stride = (int64_t)b.trace_grid * groups_per_block;
+    if (b.qwords.alloc(a.qwords.n) != hipSuccess || b.counters.alloc(a.counters.n) != hipSuccess ||
+        b.spill.alloc((size_t)(b.spill_stride * spill_levels)) != hipSuccess)
         return fail(TAKE_E_NOMEM, "out of device memory for a scene replica");
     HIP_TRY(hipMemset(b.qwords.p, 0, b.qwords.bytes()));
     HIP_TRY(hipMemset(b.counters.p, 0, b.counters.bytes()));
@@ -1229,8 +1241,13 @@ int replicate_scene(const TakeScene *src, int device, TakeScene **out) {
     ts->precision = src->precision, ts->device = device, ts->num_cus = src->num_cus, ts->instrumentation = 0;
     DeviceGuard guard(device);
     int rc = guard.ok ? TAKE_OK : fail(TAKE_E_DEVICE, "cannot make the replica's device current");
-    if (!rc) rc = src->precision == TAKE_PRECISION_F64 ? replicate_t(src->d, src->device, ts->d, device)
-                                                       : replicate_t(src->f, src->device, ts->f, device);
+    if (!rc) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ts->num_cus = cus;
+        (void)hipGetLastError();
+    }
+    if (!rc) rc = src->precision == TAKE_PRECISION_F64 ? replicate_t(src->d, src->device, src->num_cus, ts->d, device, ts->num_cus)
+                                                       : replicate_t(src->f, src->device, src->num_cus, ts->f, device, ts->num_cus);
     if (rc) {
         ts->f.release(), ts->d.release();
         delete ts;
@@ -1357,6 +1374,11 @@ int take_hip_group_create(const TakeSceneDesc *desc, const TakeBuildOpts *opts, 
         if (!rc) g->scenes.push_back(ts);
     }
     if (!rc) {
+        for (TakeScene *x : g->scenes) {  // shards that share a device share its free memory
+            int share = 0;
+            for (TakeScene *y : g->scenes) share += y->device == x->device;
+            x->mem_share = share;
+        }
         TakeScene *t0 = g->scenes[0];
         g->f64 = t0->precision == TAKE_PRECISION_F64;
         g->width = g->f64 ? t0->d.host.cam.width : t0->f.host.cam.width;

@@ -183,7 +183,10 @@ template <class R> struct HookIo {  // the C-ABI trace hooks: AoS rays in, hit r
     }
     template <bool SHADOW> __device__ __forceinline__ void reload(int64_t i, RayT<R> &ray) const {
         const RayAoS<R> q = rays[i];
-        ray = make_ray(q.org[0], q.org[1], q.org[2], q.dir[0], q.dir[1], q.dir[2], q.tmin, q.tmax);
+        // entry distances are ordered through their bit patterns, which needs tmin >= +0 (include/take_hip.h: the
+        // host entry points refuse a negative tmin; device-resident rays are clamped here: -0.0, negatives and NaN
+        // start at 0)
+        ray = make_ray(q.org[0], q.org[1], q.org[2], q.dir[0], q.dir[1], q.dir[2], q.tmin > R(0) ? q.tmin : R(0), q.tmax);
     }
     // called after store_hit by the same lane
     __device__ __forceinline__ void store_instance(int64_t i, int32_t inst) const {

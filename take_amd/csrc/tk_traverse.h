@@ -376,7 +376,10 @@ TK_HD void traverse(const DeviceScene<R> &sc, const RayT<R> &ray, Stack &stack, 
                                                              : sphere_test(p.a, ray, tbest, t);
                 // ties in t: larger (u, v), then (coincident primitives) the larger primitive index = the larger shape
                 // id (the builders order coincident primitives that way) — the same in any tree
-                if (ok && (t < tbest || hit.prim < 0 || u > hit.u || (u == hit.u && (v > hit.v || (v == hit.v && first + k > hit.prim))))) {
+                // (coincident candidates from different trees of a two-level scene: the larger instance id wins, a top-level
+                // primitive counting as instance -1 — the kernel's rule, tk_trace_quad.h — then the larger primitive index)
+                if (ok && (t < tbest || hit.prim < 0 || u > hit.u ||
+                           (u == hit.u && (v > hit.v || (v == hit.v && (hit.inst != -1 ? -1 > hit.inst : first + k > hit.prim)))))) {
                     tbest = t;
                     hit.shape = p.shape_id;
                     hit.prim = first + k;

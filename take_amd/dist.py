@@ -61,3 +61,19 @@ def render_sharded(scene, spp, max_depth, seed=0, ray_epsilon=0.0, samples_per_b
                         strip_stride=world, samples_per_batch=samples_per_batch,
                         stream=torch.cuda.current_stream().cuda_stream)
     return gather_strips(out, scene.sd.height, rank, world, group=group), out
+
+
+def multi_gpu_report(render_ms, gather_ms, group=None):
+    """What a multi-GPU bench line needs so that "did N ranks really take part, over which backend" can be read from it:
+    backend, world size as the process group reports it, and every rank's own render / gather time (all-gathered:
+    the list has one entry per rank that answered).  Works on any backend (gloo in the CPU tests, nccl = RCCL on GPUs)."""
+    if not dist.is_initialized():
+        return {"backend": None, "world_size": 1, "per_rank_render_ms": [float(render_ms)], "per_rank_gather_ms": [float(gather_ms)]}
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = "cuda" if backend == "nccl" else "cpu"
+    mine = torch.tensor([float(render_ms), float(gather_ms)], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine, group=group)
+    return {"backend": backend, "world_size": world,
+            "per_rank_render_ms": [float(t[0]) for t in every], "per_rank_gather_ms": [float(t[1]) for t in every]}

@@ -67,3 +67,30 @@ def test_negative_tmin_is_rejected(precision):
         assert len(sc.trace_closest(rays_to_abi(rays, precision))) == 64
     finally:
         sc.close()
+
+
+def test_device_resident_rays_with_bad_tmin_start_at_zero():
+    """take_hip_trace_closest_device cannot look at device-resident rays: tmin = -0.0, a negative tmin and NaN are
+    clamped to +0 in the kernel (include/take_hip.h) instead of corrupting the order keys — the hits equal those of
+    the same rays with tmin = 0"""
+    import torch
+
+    sc = capi.Scene(golden_scene("cbox"), precision=D.TAKE_PRECISION_F32)
+    try:
+        rays = random_rays(4096, 17)
+        rays[:, 6] = 0.0
+        want = sc.trace_closest(rays_to_abi(rays, 0))
+        assert (want["shape_id"] >= 0).sum() > 2000
+        flat = rays_to_abi(rays, 0).copy()  # (n, 8) float32: org3 tmin dir3 tmax
+        flat[0::3, 3] = -0.0
+        flat[1::3, 3] = -1e-3
+        flat[2::3, 3] = np.nan
+        d_rays = torch.from_numpy(flat.copy()).cuda()
+        d_hits = torch.zeros((len(rays), 4), dtype=torch.float32, device="cuda")
+        sc.trace_closest_device(d_rays.data_ptr(), len(rays), d_hits.data_ptr())
+        torch.cuda.synchronize()
+        got = np.ascontiguousarray(d_hits.cpu().numpy()).view(np.dtype([("shape_id", "<i4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])).reshape(-1)
+        for f in ("shape_id", "t", "u", "v"):
+            assert np.array_equal(got[f], want[f]), f
+    finally:
+        sc.close()

@@ -187,3 +187,63 @@ def test_gpu_shear_normals_material_override_and_memory():
     finally:
         inst.close()
         flat.close()
+
+
+def coincident_instance_scene():
+    """a quad as ordinary geometry AND, exactly coincident with it, an identity-transform placement of the same quad
+    (its own material): every ray through the quad ties in (t, u, v) between a top-level primitive and a primitive
+    inside an instance.  Rule (tk_trace_quad.h, tk_traverse.h): the larger (instance, primitive) wins, a top-level
+    primitive counting as instance -1 — so the placement's copy is the hit, in every tree and visiting order."""
+    sd = SceneData(width=32, height=32, lookfrom=(0.0, 0.0, 3.0), lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), vfov=40.0,
+                   background=(0.3, 0.3, 0.3), spp=2, max_depth=3)
+    red = sd.add_material(D.MAT_DIFFUSE, (0.8, 0.1, 0.1))
+    blue = sd.add_material(D.MAT_DIFFUSE, (0.1, 0.1, 0.8))
+    pos, idx, nrm, uv = scenes._quad((0, 0, 0), (0.7, 0, 0), (0, 0.7, 0), (0, 0, 1))
+    sd.add_mesh(pos, idx, red, normals=nrm, uvs=uv)                       # shapes 0, 1
+    far, fi, fn, fu = scenes._quad((0, 0, -1.0), (1.5, 0, 0), (0, 1.5, 0), (0, 0, 1))
+    sd.add_mesh(far, fi, red, normals=fn, uvs=fu)                         # shapes 2, 3 (a backdrop: more than one leaf)
+    proto = sd.add_prototype(pos, idx, blue, normals=nrm, uvs=uv)
+    sd.add_instance(proto, [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]])   # shapes 4, 5
+    return sd
+
+
+def _rays_at_the_quad(n, seed):
+    rng = np.random.default_rng(seed)
+    rays = np.zeros((n, 8))
+    rays[:, 0:2] = rng.uniform(-0.6, 0.6, (n, 2))
+    rays[:, 2] = 2.0
+    rays[:, 3:6] = (0.0, 0.0, -1.0)
+    rays[:, 6], rays[:, 7] = 1e-4, np.inf
+    return rays
+
+
+@pytest.mark.parametrize("precision", [1, 0])
+def test_host_instance_coincident_with_plain_geometry_tie_rule(precision):
+    sd = coincident_instance_scene()
+    rays = _rays_at_the_quad(500, 4)
+    hits = hostsim_trace(sd, precision, rays)
+    assert np.isin(hits[:, 0], (4, 5)).all()  # the placement's faces, never the coincident top-level ones (0, 1)
+    assert np.abs(hits[:, 1].astype(np.float64) - 2.0).max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [D.TAKE_PRECISION_F64, D.TAKE_PRECISION_F32])
+def test_gpu_instance_coincident_with_plain_geometry_tie_rule(precision):
+    from take_amd import capi
+
+    sd = coincident_instance_scene()
+    rays = _rays_at_the_quad(5000, 4)
+    p = 1 if precision == D.TAKE_PRECISION_F64 else 0
+    want = hostsim_trace(sd, p, rays)
+    sc = capi.Scene(sd, precision=precision)
+    try:
+        got = sc.trace_closest(rays_to_abi(rays, p))
+        assert np.isin(got["shape_id"], (4, 5)).all()
+        assert np.array_equal(got["shape_id"].astype(np.float64), want[:, 0].astype(np.float64))
+        for k, col in (("t", 1), ("u", 2), ("v", 3)):
+            assert np.array_equal(got[k].astype(np.float64), want[:, col].astype(np.float64)), k
+        img = sc.render(spp=2, max_depth=3, seed=1)
+        centre = img[12:20, 12:20].mean(axis=(0, 1))
+        assert centre[2] > centre[0]  # the quad renders in the placement's blue, not the coincident red
+    finally:
+        sc.close()
