@@ -297,6 +297,17 @@ int take_hip_render(TakeScene *scene, const TakeRenderOpts *opts, void *rgb_out_
  * `stream` (hipStream_t, NULL = default stream); returns after enqueue + sync. */
 int take_hip_render_device(TakeScene *scene, const TakeRenderOpts *opts, void *d_rgb_out,
                            void *stream);
+/* Progressive / interactive rendering: the per-pixel accumulate of the tile loop
+ * (src/render.cpp:68-78) kept resident in HBM between calls.  Renders opts->spp MORE samples per pixel on top of
+ * what the scene has accumulated since the last call with restart != 0 (or since a one-shot take_hip_render*, which
+ * ends a sequence), and writes the mean over ALL samples so far to d_rgb_out (device memory, same layout as
+ * take_hip_render_device).  The samples continue the one-shot render's numbering — same random streams, same order of
+ * the additions — so after calls with a, b, c.. samples the image equals take_hip_render(spp = a + b + c ..) BIT FOR
+ * BIT.  seed, max_depth, integrator, ray_epsilon and the strip set must stay the same within a sequence
+ * (TAKE_E_INVALID otherwise).  take_hip_accumulated_samples: samples per pixel in the accumulator. */
+int take_hip_render_accumulate(TakeScene *scene, const TakeRenderOpts *opts, int32_t restart, void *d_rgb_out,
+                               void *stream);
+int64_t take_hip_accumulated_samples(const TakeScene *scene);
 /* Egress on the device: the conversion half of the reference's imwrite("image.exr") (src/image.cpp:155-176 ->
  * tinyexr SaveEXR(components 3, fp16)).  d_rgb: height * width * 3 Real in device memory (row 0 = top, as
  * take_hip_render_device leaves it; precision says float or double) -> d_out: uint16 [height][3][width], per

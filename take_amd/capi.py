@@ -18,6 +18,7 @@ _LIB = None
 EXPORTS = [
     "take_hip_last_error", "take_hip_abi_version", "take_hip_device_count", "take_hip_scene_create",
     "take_hip_scene_destroy", "take_hip_render", "take_hip_render_device", "take_hip_render_rows",
+    "take_hip_render_accumulate", "take_hip_accumulated_samples",
     "take_hip_trace_closest", "take_hip_trace_any", "take_hip_trace_closest_device", "take_hip_get_counters",
     "take_hip_set_instrumentation", "take_hip_scene_stats", "take_hip_debug_table",
     "take_hip_group_create", "take_hip_group_destroy", "take_hip_group_render", "take_hip_group_render_device",
@@ -55,6 +56,9 @@ def lib():
         L.take_hip_scene_destroy.argtypes = [C.c_void_p]
         L.take_hip_render.argtypes = [C.c_void_p, C.POINTER(D.TakeRenderOpts), C.c_void_p]
         L.take_hip_render_device.argtypes = [C.c_void_p, C.POINTER(D.TakeRenderOpts), C.c_void_p, C.c_void_p]
+        L.take_hip_render_accumulate.argtypes = [C.c_void_p, C.POINTER(D.TakeRenderOpts), C.c_int32, C.c_void_p, C.c_void_p]
+        L.take_hip_accumulated_samples.argtypes = [C.c_void_p]
+        L.take_hip_accumulated_samples.restype = C.c_int64
         L.take_hip_render_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
         L.take_hip_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.take_hip_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]
@@ -171,6 +175,13 @@ class Scene:
         out = np.zeros((self.sd.height, 3, self.sd.width), np.uint16)
         _check(lib().take_hip_render_exr_scanlines(self.h, C.byref(o), out.ctypes.data))
         return out
+
+    def render_accumulate(self, d_ptr, more_spp, max_depth, seed=0, restart=False, ray_epsilon=0.0, strip_first=0,
+                          strip_stride=1, samples_per_batch=0, stream=None, integrator=0):
+        """progressive rendering: `more_spp` further samples per pixel, mean over all samples so far -> device buffer"""
+        o = self._opts(more_spp, max_depth, seed, ray_epsilon, strip_first, strip_stride, samples_per_batch, integrator)
+        _check(lib().take_hip_render_accumulate(self.h, C.byref(o), 1 if restart else 0, C.c_void_p(d_ptr), C.c_void_p(stream or 0)))
+        return int(lib().take_hip_accumulated_samples(self.h))
 
     def trace_closest(self, rays_abi):
         """rays_abi: (n,8) array in TakeRayF/D layout (org3 tmin dir3 tmax) -> structured hits"""

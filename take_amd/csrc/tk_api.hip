@@ -55,6 +55,40 @@ inline bool inject_alloc_failure() {
     return ++calls == std::atol(e);
 }
 
+// Host -> device copies of the caller's large arrays (mesh positions, shape arrays) for the device-side scene build
+// (SURVEY.md §8(f)2): the pages are pinned IN PLACE (hipHostRegister) so that the DMA engine reads the caller's memory
+// directly — no bounce through the runtime's staging buffers — and the copies of all arrays are in flight together;
+// the registrations are dropped once the stream has drained.  Arrays below 4 MiB, and memory that cannot be
+// registered, take the ordinary pageable path.  TAKE_HIP_PINNED_UPLOAD=0 turns the registration off (A/B runs).
+struct PinnedUploads {
+    hipStream_t stream = nullptr;
+    std::vector<void *> regs;
+    size_t pinned_bytes = 0, plain_bytes = 0;
+    bool enabled = !(std::getenv("TAKE_HIP_PINNED_UPLOAD") && std::atoi(std::getenv("TAKE_HIP_PINNED_UPLOAD")) == 0);
+    hipError_t copy(void *dst, const void *src, size_t bytes) {
+        if (bytes == 0) return hipSuccess;
+        if (enabled && bytes >= ((size_t)4 << 20)) {
+            if (hipHostRegister(const_cast<void *>(src), bytes, hipHostRegisterDefault) == hipSuccess) {
+                regs.push_back(const_cast<void *>(src));
+                pinned_bytes += bytes;
+            } else {
+                (void)hipGetLastError();  // (already registered, read-only mapping, ...): pageable copy
+                plain_bytes += bytes;
+            }
+        } else {
+            plain_bytes += bytes;
+        }
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+    }
+    hipError_t finish() {
+        const hipError_t e = hipStreamSynchronize(stream);
+        for (void *p : regs) (void)hipHostUnregister(p);
+        regs.clear();
+        return e;
+    }
+    ~PinnedUploads() { (void)finish(); }
+};
+
 template <class T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
@@ -158,6 +192,9 @@ struct TakeScene {
     int precision = TAKE_PRECISION_F32;
     int device = 0;
     int num_cus = 256;
+    // progressive rendering (take_hip_render_accumulate): samples per pixel summed in `accum` so far, under which options
+    int64_t acc_samples = 0;
+    TakeRenderOpts acc_opts{};
     int mem_share = 1;  // scenes of one group on this device: each sizes its path-state batch for 1/mem_share of the free HBM
     int instrumentation = 0;
     SceneT<float> f;
@@ -322,14 +359,14 @@ int make_prims_on_device(SceneT<float> &sc, const TakeSceneDesc &d) {
         ~Cleanup() { f(); }
     } cleanup{[&] { d_pos.release(), d_kind.release(), d_ref.release(), d_face.release(), d_al.release(), d_ms.release(), d_ss.release(); }};
     HIP_TRY(d_pos.alloc(3 * (size_t)std::max<int64_t>(nv, 1)));
+    PinnedUploads pin;
     for (int i = 0; i < d.n_meshes; i++)
         if (d.meshes[i].n_vertices > 0)
-            HIP_TRY(hipMemcpyAsync(d_pos.p + 3 * ms[i].pos_off, d.meshes[i].positions, sizeof(double) * 3 * (size_t)d.meshes[i].n_vertices,
-                                   hipMemcpyHostToDevice, nullptr));
+            HIP_TRY(pin.copy(d_pos.p + 3 * ms[i].pos_off, d.meshes[i].positions, sizeof(double) * 3 * (size_t)d.meshes[i].n_vertices));
     HIP_TRY(sc.face_idx.upload(h.face_idx));
     auto up = [&](DevBuf<int32_t> &b, const int32_t *src) -> hipError_t {
         hipError_t e = b.alloc((size_t)n);
-        return e != hipSuccess ? e : hipMemcpyAsync(b.p, src, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, nullptr);
+        return e != hipSuccess ? e : pin.copy(b.p, src, sizeof(int32_t) * (size_t)n);
     };
     HIP_TRY(up(d_kind, d.shape_kind));
     HIP_TRY(up(d_ref, d.shape_ref));
@@ -341,7 +378,9 @@ int make_prims_on_device(SceneT<float> &sc, const TakeSceneDesc &d) {
     hipLaunchKernelGGL(k_make_prims, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, nullptr, d_kind.p, d_ref.p, d_face.p, d_al.p,
                        d_ms.p, d_pos.p, sc.face_idx.p, d_ss.p, n, sc.prims.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(pin.finish());  // (the kernel is behind the copies on the same stream)
+    if (std::getenv("TAKE_HIP_VERBOSE"))
+        std::fprintf(stderr, "[take_hip] scene_create: uploads pinned in place %.1f MB, pageable %.1f MB\n", pin.pinned_bytes / 1e6, pin.plain_bytes / 1e6);
     return TAKE_OK;
 }
 template <class R> int make_prims_on_device(SceneT<R> &, const TakeSceneDesc &) { return 1; }
@@ -659,8 +698,13 @@ template <class R> void dump_slot(const PathState<R> &st, int64_t slot, const ch
     std::fprintf(stderr, "\n");
 }
 
-template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void *d_out, hipStream_t stream) {
+// first_sample / keep_accum: progressive rendering — the samples of this call are numbered from first_sample (their
+// random streams are those of a one-shot render's samples first_sample .. first_sample + spp - 1), keep_accum adds them
+// to what `accum` holds instead of starting from zero, and the image is the mean over first_sample + spp samples.
+template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void *d_out, hipStream_t stream,
+                                   int64_t first_sample = 0, bool keep_accum = false) {
     SceneT<R> &sc = pick<R>(ts);
+    if (!keep_accum) ts->acc_samples = 0;  // (a one-shot render overwrites the accumulator: a progressive sequence ends)
     const int W = sc.host.cam.width, H = sc.host.cam.height;
     if (o.spp <= 0) return fail(TAKE_E_INVALID, "spp must be positive");
     if (o.max_depth < -1) return fail(TAKE_E_INVALID, "max_depth must be >= -1");
@@ -733,7 +777,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
             HIP_TRY(sc.sort_base.alloc(need));
         }
     }
-    HIP_TRY(hipMemsetAsync(sc.accum.p, 0, sizeof(R) * 3 * npix, stream));
+    if (!keep_accum) HIP_TRY(hipMemsetAsync(sc.accum.p, 0, sizeof(R) * 3 * npix, stream));
     HIP_TRY(hipMemsetAsync(sc.counters.p, 0, sc.counters.bytes(), stream));
     hipEvent_t ev_begin = ts->events.get(), ev_end = ts->events.get();
     HIP_TRY(hipEventRecord(ev_begin, stream));
@@ -746,7 +790,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     for (int s0 = 0; s0 < o.spp; s0 += spb) {
         const int nb = std::min(spb, o.spp - s0);
         const int64_t n = (int64_t)nb * npix;
-        rp.s0 = s0;
+        rp.s0 = (int32_t)first_sample + s0;
         rp.spb = nb;
         tm.begin(TK_OTHER);
         hipLaunchKernelGGL((k_generate<R>), dim3(wide_grid), dim3(BLOCK), 0, stream, sc.dev, rp, st, sc.queue[0].p, n);
@@ -838,7 +882,8 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
         tm.end();
     }
     tm.begin(TK_OTHER);
-    hipLaunchKernelGGL((k_resolve<R>), dim3(pix_grid), dim3(BLOCK), 0, stream, sc.accum.p, (R *)d_out, W, n_rows, o.spp);
+    hipLaunchKernelGGL((k_resolve<R>), dim3(pix_grid), dim3(BLOCK), 0, stream, sc.accum.p, (R *)d_out, W, n_rows,
+                       (int32_t)first_sample + o.spp);
     tm.end();
     HIP_TRY(hipEventRecord(ev_end, stream));
     HIP_TRY(hipGetLastError());
@@ -1044,6 +1089,33 @@ int take_hip_render_device(TakeScene *ts, const TakeRenderOpts *opts, void *d_rg
     if (ts->precision == TAKE_PRECISION_F64) return render_impl<double>(ts, *opts, d_rgb_out, (hipStream_t)stream);
     return render_impl<float>(ts, *opts, d_rgb_out, (hipStream_t)stream);
 }
+
+// Progressive rendering (the per-pixel accumulate of src/render.cpp:68-78 kept resident between calls).
+int take_hip_render_accumulate(TakeScene *ts, const TakeRenderOpts *opts, int32_t restart, void *d_rgb_out, void *stream) {
+    if (!ts || !opts || !d_rgb_out) return fail(TAKE_E_INVALID, "null argument");
+    TAKE_ON_DEVICE(ts);
+    const bool f64 = ts->precision == TAKE_PRECISION_F64;
+    const TakeRenderOpts &a = ts->acc_opts;
+    const bool fresh = restart != 0 || ts->acc_samples == 0;
+    if (!fresh && (a.seed != opts->seed || a.max_depth != opts->max_depth || a.integrator != opts->integrator ||
+                   a.strip_first != opts->strip_first || a.strip_stride != opts->strip_stride || a.ray_epsilon != opts->ray_epsilon))
+        return fail(TAKE_E_INVALID, "take_hip_render_accumulate: options differ from the ones the accumulated samples were "
+                                    "rendered with (seed, max_depth, integrator, strips, ray_epsilon): pass restart = 1");
+    const int64_t first = fresh ? 0 : ts->acc_samples;
+    if (first + (int64_t)opts->spp >= ((int64_t)1 << 31)) return fail(TAKE_E_INVALID, "too many accumulated samples");
+    // (a workspace grown for a bigger batch keeps the accumulator: ensure_workspace only ever enlarges it, and the
+    // strip set — hence the pixel count — is fixed for the sequence)
+    const int rc = f64 ? render_impl<double>(ts, *opts, d_rgb_out, (hipStream_t)stream, first, !fresh)
+                       : render_impl<float>(ts, *opts, d_rgb_out, (hipStream_t)stream, first, !fresh);
+    if (rc) {
+        ts->acc_samples = 0;  // the accumulator may hold a partial batch: the sequence has to restart
+        return rc;
+    }
+    ts->acc_samples = first + opts->spp;
+    ts->acc_opts = *opts;
+    return TAKE_OK;
+}
+int64_t take_hip_accumulated_samples(const TakeScene *ts) { return ts ? ts->acc_samples : 0; }
 
 int take_hip_render(TakeScene *ts, const TakeRenderOpts *opts, void *rgb_out_host) {
     if (!ts || !opts || !rgb_out_host) return fail(TAKE_E_INVALID, "null argument");

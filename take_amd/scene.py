@@ -141,6 +141,7 @@ class SceneData:
         out.shape_face, out.shape_area_light = self.shape_face.copy(), self.shape_area_light.copy()
         out.lights = list(self.lights)
         out.instance_mesh, out.instance_material, out.instance_xform = [], [], []
+        kinds, refs, faces, als = [out.shape_kind], [out.shape_ref], [out.shape_face], [out.shape_area_light]
         for mid, mat, x in zip(self.instance_mesh, self.instance_material, self.instance_xform):
             m = self.meshes[mid]
             pos = m.positions @ x[:, :3].T + x[:, 3]
@@ -149,7 +150,14 @@ class SceneData:
                 # rows: (L^-T n)^T = n^T L^-1; NOT re-normalised per vertex — interpolation commutes with the linear
                 # map only then (the interpolated normal is normalised at the hit, src/shape.cpp:105)
                 nrm = m.normals @ np.linalg.inv(x[:, :3])
-            out.add_mesh(pos, m.indices, m.material_id if mat < 0 else mat, normals=nrm, uvs=m.uvs)
+            # (add_mesh, with the four shape arrays concatenated once at the end: 1000 placements of 10k triangles)
+            nf = m.indices.shape[0]
+            out.meshes.append(Mesh(np.ascontiguousarray(pos, np.float64), m.indices, m.material_id if mat < 0 else mat,
+                                   None if nrm is None else np.ascontiguousarray(nrm, np.float64), m.uvs))
+            kinds.append(np.ones(nf, np.int32)), refs.append(np.full(nf, len(out.meshes) - 1, np.int32))
+            faces.append(np.arange(nf, dtype=np.int32)), als.append(np.full(nf, -1, np.int32))
+        out.shape_kind, out.shape_ref = np.concatenate(kinds), np.concatenate(refs)
+        out.shape_face, out.shape_area_light = np.concatenate(faces), np.concatenate(als)
         return out
 
     def add_envmap(self, image, scale=(1.0, 1.0, 1.0)):
