@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAKE_HIP_ABI_VERSION 2 /* 2: TakeSceneDesc.instances, TakeRenderOpts.integrator (was reserved) */
+#define TAKE_HIP_ABI_VERSION 3 /* 2: TakeSceneDesc.instances, TakeRenderOpts.integrator (was reserved); 3: take_hip_render_accumulate */
 
 /* error codes */
 #define TAKE_OK 0
