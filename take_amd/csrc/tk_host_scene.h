@@ -298,19 +298,43 @@ std::string build_host_trees(const TakeSceneDesc &d, HostScene<R> &hs, std::vect
         is.shape_base = (int32_t)shape_next;
         shape_next += m.n_faces;
         if (shape_next >= (int64_t)1 << 31) return "too many instanced faces for 32-bit shape ids";
-        // world box of the placement: the object box's corners under the transform, padded for the rounding of
-        // the transformed ray (the specification is the flattened geometry to fp rounding, see take_hip.h)
+        // World box of the placement, padded for the rounding of the transformed ray (the specification is the
+        // flattened geometry to fp rounding, see take_hip.h).  The TIGHT box: the prototype's vertices under the
+        // transform — the object box's eight corners under a rotation span up to sqrt(3) times the extent per axis (5x
+        // the volume for a round cloud), and every ray that enters a placement's box pays a descent from the prototype's
+        // root (round 2: instanced 42 vs flattened 66 Msamples/s on 1000 x 10k triangles).  Beyond 4e8 vertex
+        // transforms in total: the corners' box intersected with the box of the bounding sphere's image.
         BuildPrim ib;
         ib.id = -(int32_t)(i + 1);
         for (int a = 0; a < 3; a++) ib.bmin[a] = std::numeric_limits<double>::infinity(), ib.bmax[a] = -ib.bmin[a];
         double mag = 0;
-        for (int c8 = 0; c8 < 8; c8++) {
-            const double px = (c8 & 1) ? b.hi[0] : b.lo[0], py = (c8 & 2) ? b.hi[1] : b.lo[1], pz = (c8 & 4) ? b.hi[2] : b.lo[2];
-            for (int a = 0; a < 3; a++) {
-                const double w = M[4 * a] * px + M[4 * a + 1] * py + M[4 * a + 2] * pz + M[4 * a + 3];
-                ib.bmin[a] = std::min(ib.bmin[a], w), ib.bmax[a] = std::max(ib.bmax[a], w);
-                mag = std::max(mag, std::fabs(w));
+        if ((double)m.n_vertices * (double)d.n_instances <= 4e8) {
+            for (int64_t vtx = 0; vtx < m.n_vertices; vtx++) {
+                const double px = m.positions[3 * vtx], py = m.positions[3 * vtx + 1], pz = m.positions[3 * vtx + 2];
+                for (int a = 0; a < 3; a++) {
+                    const double w = M[4 * a] * px + M[4 * a + 1] * py + M[4 * a + 2] * pz + M[4 * a + 3];
+                    ib.bmin[a] = std::min(ib.bmin[a], w), ib.bmax[a] = std::max(ib.bmax[a], w);
+                }
             }
+            for (int a = 0; a < 3; a++) mag = std::max(mag, std::max(std::fabs(ib.bmin[a]), std::fabs(ib.bmax[a])));
+        } else {
+            for (int c8 = 0; c8 < 8; c8++) {
+                const double px = (c8 & 1) ? b.hi[0] : b.lo[0], py = (c8 & 2) ? b.hi[1] : b.lo[1], pz = (c8 & 4) ? b.hi[2] : b.lo[2];
+                for (int a = 0; a < 3; a++) {
+                    const double w = M[4 * a] * px + M[4 * a + 1] * py + M[4 * a + 2] * pz + M[4 * a + 3];
+                    ib.bmin[a] = std::min(ib.bmin[a], w), ib.bmax[a] = std::max(ib.bmax[a], w);
+                }
+            }
+            // image of the object box's bounding sphere: centre M c, radius r * ||L||_F per axis row
+            double c[3], r2 = 0;
+            for (int a = 0; a < 3; a++) c[a] = 0.5 * (b.lo[a] + b.hi[a]), r2 += 0.25 * (b.hi[a] - b.lo[a]) * (b.hi[a] - b.lo[a]);
+            const double r = std::sqrt(r2);
+            for (int a = 0; a < 3; a++) {
+                const double wc = M[4 * a] * c[0] + M[4 * a + 1] * c[1] + M[4 * a + 2] * c[2] + M[4 * a + 3];
+                const double wr = r * std::sqrt(M[4 * a] * M[4 * a] + M[4 * a + 1] * M[4 * a + 1] + M[4 * a + 2] * M[4 * a + 2]) * (1.0 + 1e-12);
+                ib.bmin[a] = std::max(ib.bmin[a], wc - wr), ib.bmax[a] = std::min(ib.bmax[a], wc + wr);
+            }
+            for (int a = 0; a < 3; a++) mag = std::max(mag, std::max(std::fabs(ib.bmin[a]), std::fabs(ib.bmax[a])));
         }
         const double pad = mag * (sizeof(R) == 4 ? 4e-6 : 1e-13);
         for (int a = 0; a < 3; a++) ib.bmin[a] -= pad, ib.bmax[a] += pad;

@@ -69,8 +69,14 @@ template <class R> struct RecordView {
     __device__ __forceinline__ R &R_(int c, int64_t) const { return w[c]; }
     __device__ __forceinline__ int32_t &I_(int c, int64_t) const { return *reinterpret_cast<int32_t *>(&w[c]); }
 };
+#ifndef TK_SHADE_WAVES_F32
+#define TK_SHADE_WAVES_F32 0  // register cap of the shade kernels in waves per SIMD (0: none): tuning knob, DESIGN.md §7
+#endif
+#ifndef TK_SHADE_WAVES_F64
+#define TK_SHADE_WAVES_F64 0
+#endif
 template <class R, int TAG, bool ALT = false>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK, (sizeof(R) == 4 ? TK_SHADE_WAVES_F32 : TK_SHADE_WAVES_F64) > 0 ? (sizeof(R) == 4 ? TK_SHADE_WAVES_F32 : TK_SHADE_WAVES_F64) : 1)
 k_shade(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, const int32_t *__restrict__ queue,
         const int32_t *__restrict__ n_ptr, const int32_t *__restrict__ tag_count, int32_t *next_queue,
         int32_t *n_next, int32_t *shadow_queue, int32_t *n_shadow, int k, unsigned long long *counters) {

@@ -67,7 +67,7 @@ int main(int argc, char **argv) {
     const int root = builder.build();
     const auto &n2 = builder.nodes();
     const int slot_mode = std::getenv("LAB_SLOTS") ? std::atoi(std::getenv("LAB_SLOTS")) : 1;  // 0 as opened, 1 octant auction
-    for (int Wd : {4, 8}) {
+    for (int Wd : {2, 3, 4, 5, 6, 8}) {
         std::vector<WNode> wn;
         std::vector<int32_t> worder;
         std::vector<int> queue{root};
@@ -192,7 +192,7 @@ int main(int argc, char **argv) {
                                         c.child = w.child[j];
                                         float tn;
                                         ub[t]++;
-                                        if (box_test(c, ray.o, idx, idy, idz, ray.tmin, tbest, tn)) hc[nh] = c.child, hk[nh] = tn, hp[nh] = j ^ (oct & (Wd - 1)), nh++;
+                                        if (box_test(c, ray.o, idx, idy, idz, ray.tmin, tbest, tn)) hc[nh] = c.child, hk[nh] = tn, hp[nh] = (Wd == 8 ? j ^ oct : j), nh++;
                                     }
                                     // order the hits: index 0 = visited next
                                     auto swp = [&](int a, int b) { std::swap(hk[a], hk[b]), std::swap(hc[a], hc[b]), std::swap(hp[a], hp[b]); };
