@@ -218,14 +218,29 @@ std::string build_host_trees(const TakeSceneDesc &d, HostScene<R> &hs, std::vect
         int32_t root_child = CHILD_EMPTY;
         double lo[3], hi[3];
         int depth = 0;
+        // "re-braiding" (Benthin et al. 2017): the entries a placement contributes to the top-level build — subtrees
+        // of the prototype's tree (child word local to this tree + object-space box), the root opened largest box
+        // first until `braid` entries exist.  Built and MEASURED in round 3 on configs[4] (1000 placements x 10k
+        // triangles, boxes of 0.16 overlapping in a 1.7 box): 1 / 4 / 8 / 16 / 32 / 64 entries per placement = 45.0 /
+        // 40.7 / 39.0 / 36.8 / 35.1 / 34.1 Msamples/s — every entry a ray enters costs a 96-byte record, a transform
+        // and a return marker, and the entries of one placement overlap (their boxes are the corners' boxes of
+        // rotated object boxes); that outweighs the shorter descents.  Default 1 (TAKE_HIP_BRAID overrides).
+        struct Entry {
+            int32_t word;
+            double lo[3], hi[3];
+        };
+        std::vector<Entry> entries;
     };
+    const char *braid_env = std::getenv("TAKE_HIP_BRAID");
+    const int braid = std::max(1, std::min(braid_env ? std::atoi(braid_env) : 1, 64));
     std::vector<Blas> blas;
     std::vector<int> blas_of_mesh(d.n_meshes, -1);
-    std::vector<int> inst_blas(d.n_instances, -1);
+    std::vector<int> inst_blas;  // per (virtual) instance: its prototype tree
     int max_blas_depth = 0;
     int64_t shape_next = ns;
-    hs.inst_trace.assign(d.n_instances, InstTrace<R>{});
-    hs.inst_shade.assign(d.n_instances, InstShade<R>{});
+    // one InstTrace / InstShade per ENTRY of a placement ("virtual instances", placement-major: the tie rule on the
+    // instance id keeps ordering placements as the caller numbered them)
+    hs.inst_trace.clear(), hs.inst_shade.clear();
     for (int64_t i = 0; i < d.n_instances; i++) {
         const TakeInstance &in = d.instances[i];
         if (in.mesh_id < 0 || in.mesh_id >= d.n_meshes) return "instance " + std::to_string(i) + ": bad mesh id";
@@ -274,9 +289,36 @@ std::string build_host_trees(const TakeSceneDesc &d, HostScene<R> &hs, std::vect
             for (size_t k = 0; k < border.size(); k++) b.prims[k] = brecs[bbp[border[k]].id];
             order_coincident(b.prims, 0, b.prims.size());
             max_blas_depth = std::max(max_blas_depth, b.depth);
+            typename Blas::Entry root_e;
+            root_e.word = b.root_child;
+            for (int a = 0; a < 3; a++) root_e.lo[a] = b.lo[a], root_e.hi[a] = b.hi[a];
+            b.entries.assign(1, root_e);
+            while ((int)b.entries.size() < braid) {
+                int best = -1;
+                double best_area = -1;
+                for (size_t e = 0; e < b.entries.size(); e++) {
+                    if (b.entries[e].word < 0) continue;  // a leaf
+                    Bounds bb2;
+                    bb2.grow(b.entries[e].lo, b.entries[e].hi);
+                    if (bb2.half_area() > best_area) best_area = bb2.half_area(), best = (int)e;
+                }
+                if (best < 0) break;
+                const NodeW<R, W> &nd = b.nodes[b.entries[best].word];
+                int nkids = 0;
+                for (int j = 0; j < W; j++) nkids += nd.c[j].child != CHILD_EMPTY;
+                if ((int)b.entries.size() - 1 + nkids > braid) break;
+                b.entries.erase(b.entries.begin() + best);
+                for (int j = 0; j < W; j++) {
+                    if (nd.c[j].child == CHILD_EMPTY) continue;
+                    typename Blas::Entry e;
+                    e.word = nd.c[j].child;
+                    for (int a = 0; a < 3; a++) e.lo[a] = (double)nd.c[j].bmin[a], e.hi[a] = (double)nd.c[j].bmax[a];
+                    b.entries.push_back(e);
+                }
+            }
         }
-        inst_blas[i] = blas_of_mesh[in.mesh_id];
-        const Blas &b = blas[inst_blas[i]];
+        const int this_blas = blas_of_mesh[in.mesh_id];
+        const Blas &b = blas[this_blas];
         // transforms: forward linear part for shading, inverse (in double) for the ray
         const double *M = in.xform;
         const double a00 = M[0], a01 = M[1], a02 = M[2], a10 = M[4], a11 = M[5], a12 = M[6], a20 = M[8], a21 = M[9], a22 = M[10];
@@ -285,12 +327,12 @@ std::string build_host_trees(const TakeSceneDesc &d, HostScene<R> &hs, std::vect
         const double inv[9] = {(a11 * a22 - a12 * a21) / det, (a02 * a21 - a01 * a22) / det, (a01 * a12 - a02 * a11) / det,
                                (a12 * a20 - a10 * a22) / det, (a00 * a22 - a02 * a20) / det, (a02 * a10 - a00 * a12) / det,
                                (a10 * a21 - a11 * a20) / det, (a01 * a20 - a00 * a21) / det, (a00 * a11 - a01 * a10) / det};
-        InstTrace<R> &it = hs.inst_trace[i];
+        InstTrace<R> it{};
         for (int r = 0; r < 3; r++) {
             for (int c = 0; c < 3; c++) it.inv[4 * r + c] = R(inv[3 * r + c]);
             it.inv[4 * r + 3] = R(-(inv[3 * r] * M[3] + inv[3 * r + 1] * M[7] + inv[3 * r + 2] * M[11]));
         }
-        InstShade<R> &is = hs.inst_shade[i];
+        InstShade<R> is{};
         for (int r = 0; r < 3; r++)
             for (int c = 0; c < 3; c++) is.fwd[3 * r + c] = R(M[4 * r + c]);
         is.material = in.material_id >= 0 ? in.material_id : m.material_id;
@@ -337,9 +379,34 @@ std::string build_host_trees(const TakeSceneDesc &d, HostScene<R> &hs, std::vect
             for (int a = 0; a < 3; a++) mag = std::max(mag, std::max(std::fabs(ib.bmin[a]), std::fabs(ib.bmax[a])));
         }
         const double pad = mag * (sizeof(R) == 4 ? 4e-6 : 1e-13);
-        for (int a = 0; a < 3; a++) ib.bmin[a] -= pad, ib.bmax[a] += pad;
-        bp.push_back(ib);
+        // one top-level entry per braid entry of the prototype: the entry's object box under the transform (its eight
+        // corners), clipped to the placement's box, padded
+        for (const typename Blas::Entry &e : b.entries) {
+            BuildPrim eb;
+            const int64_t vid = (int64_t)hs.inst_trace.size();
+            if (vid >= ((int64_t)1 << 28)) return "too many instance entries";
+            eb.id = -(int32_t)(vid + 1);
+            for (int a = 0; a < 3; a++) eb.bmin[a] = std::numeric_limits<double>::infinity(), eb.bmax[a] = -eb.bmin[a];
+            for (int c8 = 0; c8 < 8; c8++) {
+                const double px = (c8 & 1) ? e.hi[0] : e.lo[0], py = (c8 & 2) ? e.hi[1] : e.lo[1], pz = (c8 & 4) ? e.hi[2] : e.lo[2];
+                for (int a = 0; a < 3; a++) {
+                    const double w = M[4 * a] * px + M[4 * a + 1] * py + M[4 * a + 2] * pz + M[4 * a + 3];
+                    eb.bmin[a] = std::min(eb.bmin[a], w), eb.bmax[a] = std::max(eb.bmax[a], w);
+                }
+            }
+            for (int a = 0; a < 3; a++) {
+                eb.bmin[a] = std::max(eb.bmin[a], ib.bmin[a]) - pad, eb.bmax[a] = std::min(eb.bmax[a], ib.bmax[a]) + pad;
+                if (eb.bmin[a] > eb.bmax[a]) eb.bmin[a] = eb.bmax[a] = 0.5 * (eb.bmin[a] + eb.bmax[a]);  // (rounding of a flat entry)
+            }
+            bp.push_back(eb);
+            InstTrace<R> ie = it;
+            ie.root_child = e.word;  // local to the prototype's tree for now: made global below
+            hs.inst_trace.push_back(ie);
+            hs.inst_shade.push_back(is);
+            inst_blas.push_back(this_blas);
+        }
     }
+    const int64_t n_virtual = (int64_t)hs.inst_trace.size();
 
     Bvh2Builder builder(bp, leaf_size, threads);
     const int root = builder.build();
@@ -372,7 +439,12 @@ std::string build_host_trees(const TakeSceneDesc &d, HostScene<R> &hs, std::vect
     }
     hs.stats.n_nodes = (int64_t)nodes.size();
     hs.stats.depth += max_blas_depth;  // the traversal stack holds both levels (+ one return marker)
-    for (int64_t i = 0; i < d.n_instances; i++) hs.inst_trace[i].root_child = blas[inst_blas[i]].root_child;
+    for (int64_t i = 0; i < n_virtual; i++) {  // entry words: local to the prototype's tree -> global
+        const int k = inst_blas[i];
+        const int32_t c = hs.inst_trace[i].root_child;
+        hs.inst_trace[i].root_child = c == CHILD_EMPTY ? c : (c >= 0 ? c + (int32_t)blas_node_base[k]
+                                                                     : make_leaf(leaf_first(c) + (int32_t)blas_prim_base[k], leaf_count(c)));
+    }
 
     qnodes.clear();
     {
@@ -396,7 +468,7 @@ std::string build_host_trees(const TakeSceneDesc &d, HostScene<R> &hs, std::vect
                 qnodes.insert(qnodes.end(), q.begin(), q.end());
                 grids[k] = {glo[0], glo[1], glo[2], gst[0], gst[1], gst[2]};
             }
-            for (int64_t i = 0; i < d.n_instances; i++)
+            for (int64_t i = 0; i < n_virtual; i++)
                 for (int a = 0; a < 3; a++)
                     hs.inst_trace[i].grid_lo[a] = grids[inst_blas[i]][a], hs.inst_trace[i].grid_step[a] = grids[inst_blas[i]][3 + a];
             if (hs.q_inflation > 1.10 && fmt != "q16") qnodes.clear();
