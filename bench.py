@@ -19,12 +19,14 @@ string says so.  `--config 3` is BASELINE configs[3] — the north-star's ">= 6x
 For N > 1 the line carries `multi_gpu`: backend, world size as the process group reports it, every rank's render and
 gather milliseconds.
 
-Precision: `value` is measured on the REFERENCE's arithmetic (Real = double, src/take.h:27): the f64 device path,
-whose images agree with the pinned oracle at rounding level (tests/test_gpu_parity.py) — the path that meets the
-north-star's per-pixel RMSE < 1e-3.  At N = 1 the same workload is also timed on the f32 device path
-(`production_f32`, `--alt-steps` steps), and `parity` reports the per-pixel RMSE between the two legs' images of this
-very workload at matched seeds (f32 sits at ~1.8e-3 on the 1M soup: faster, but outside the tolerance, so it is not
-the headline).  `--precision f32` swaps the roles.
+Precision: `value` is measured on the MIXED-precision device path (TAKE_PRECISION_MIXED): every path's first three
+rounds — camera ray and the next two bounces, where a flipped hit / miss decision costs the most radiance — run in the
+reference's arithmetic (Real = double, src/take.h:27) on the f64 scene, the surviving paths continue on f32 records and
+the f32 scene.  The line carries its own proof: at N = 1 the same workload is also timed on the pure f64 path
+(`reference_precision`: images at rounding level of the pinned oracle, tests/test_gpu_parity.py) and on the pure f32
+path (`production_f32`), and `parity` reports the per-pixel RMSE of the mixed image and of the f32 image against the
+f64 image of this very workload at matched seeds (north-star tolerance: 1e-3; f32 alone sits at ~1.8e-3 on the 1M
+soup, the mixed path at ~0.6e-3).  `--precision f64` / `f32` make one of the pure paths the headline.
 
 One JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel
 (closest-hit traversal, measured with HIP events inside the timed region) and `cpu_baseline` (rank 0, N = 1 only).
@@ -75,11 +77,13 @@ def parse_args():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3],
                     help="BASELINE.json configs index: 2 = 1920x1080x256 spp per GPU (weak scaling, default); 3 = 4096x4096, "
                          "1024 spp total, rows sharded over the ranks (strong scaling)")
-    ap.add_argument("--precision", default="f64", choices=["f32", "f64"],
-                    help="arithmetic of the timed steps (`value`): f64 = the reference's Real (default: the path that meets "
-                         "the RMSE tolerance); f32 = the faster production arithmetic")
+    ap.add_argument("--precision", default="mixed", choices=["f32", "f64", "mixed"],
+                    help="arithmetic of the timed steps (`value`): mixed = first --exact-bounces rounds in f64, the rest in f32 "
+                         "(default: meets the RMSE tolerance, see `parity`); f64 = the reference's Real throughout; f32 = the "
+                         "production arithmetic throughout")
+    ap.add_argument("--exact-bounces", type=int, default=0, help="mixed precision: rounds computed in f64 (0 = the library's default, 3)")
     ap.add_argument("--alt-steps", "--f64-steps", dest="alt_steps", type=int, default=2,
-                    help="timed steps of the same workload on the OTHER precision's device path, N = 1 only; 0 = skip")
+                    help="timed steps of the same workload on each of the OTHER precisions' device paths, N = 1 only; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="640x360x1", help="WxHxSPP of the CPU-baseline sample")
     args = ap.parse_args()
@@ -186,7 +190,7 @@ def roofline_of(args, precision, bytes_per_ray, acc, node_bytes):
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     pmc = measured_counters(args, precision)
     fabric = pmc["traffic"] / (avg_ms * 1e-3) / 1e9 if (pmc["traffic"] and avg_ms > 0) else None
-    rtype = "double" if precision == "f64" else "float"
+    rtype = "double" if precision == "f64" else "float"  # (mixed: the f32 instance runs all rounds but the first three)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": pmc["traffic"], "traffic_source": pmc["source"],
             "fabric_GBps": fabric, "fabric_frac": fabric / HBM_PEAK_GBS if fabric else None,
@@ -215,11 +219,13 @@ def run_leg(args, sd, precision, steps, warmup, rank, world, backend, spp_total,
     from take_amd import cdefs as D
     from take_amd.dist import gather_strips, multi_gpu_report, strip_rows
 
-    f64 = precision == "f64"
+    f64 = precision != "f32"  # (records and images of the mixed path are doubles)
     t0 = time.time()
-    scene = capi.Scene(sd, precision=D.TAKE_PRECISION_F64 if f64 else D.TAKE_PRECISION_F32, max_leaf_size=args.max_leaf,
+    scene = capi.Scene(sd, precision={"f32": D.TAKE_PRECISION_F32, "f64": D.TAKE_PRECISION_F64, "mixed": D.TAKE_PRECISION_MIXED}[precision],
+                       max_leaf_size=args.max_leaf,
                        builder={"device": D.TAKE_BUILDER_DEVICE_LBVH, "host": D.TAKE_BUILDER_HOST_SAH, "auto": D.TAKE_BUILDER_AUTO}[args.builder])
     t_setup = time.time() - t0
+    scene.exact_bounces = args.exact_bounces
     stats = scene.stats()
     rows = strip_rows(args.height, rank, world)
     out = torch.empty((len(rows), args.width, 3), dtype=torch.float64 if f64 else torch.float32, device="cuda")
@@ -235,7 +241,7 @@ def run_leg(args, sd, precision, steps, warmup, rank, world, backend, spp_total,
     cc = scene.counters()
     rays_counted = cc["rays_closest"] + cc["rays_shadow"]
     bytes_per_ray = ((cc["node_visits"] * cc["node_bytes"] + cc["prim_tests"] * cc["prim_bytes"]) / max(rays_counted, 1)
-                     + (2 * STATE_BYTES_PER_RAY - 4 if f64 else STATE_BYTES_PER_RAY))
+                     + (2 * STATE_BYTES_PER_RAY - 4 if precision == "f64" else STATE_BYTES_PER_RAY))
     scene.set_instrumentation(timing=True, counting=False)
     if warmup == 0 and not is_main:
         # (secondary leg: kernels loaded AND the batch workspace of the timed steps allocated — a first hipMalloc of
@@ -336,7 +342,7 @@ def main():
             "metric": f"Msamples/s (camera paths/s: rays traced x spp / s), 1M-tri soup; {mode}",
             "value": main_leg["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_leg["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "vs_baseline": None, "dtype": {"mixed": "f64+f32"}.get(args.precision, args.precision), "data": "synthetic",
             "config": {"workload": (f"{args.instanced} placements x triangles ({'flattened to world space' if args.flatten else 'two-level instancing'}, 7 BSDFs round-robin)" if args.instanced else
                                     f"procedural {args.tris}-triangle soup ({args.materials} materials)")
                                    + " in 5-wall box + 1 quad area light, "
@@ -346,8 +352,11 @@ def main():
                                    f"{args.max_depth}, no Russian roulette, "
                                    + ("procedural sky env-map 2048x1024, importance-sampled (extension)" if args.envmap
                                       else "constant background (no env-map IBL upstream)"),
-                       "arithmetic": "f64 = the reference's Real (src/take.h:27); images at rounding level of the pinned oracle"
-                                     if args.precision == "f64" else "f32 production arithmetic (see parity)",
+                       "arithmetic": {"f64": "f64 = the reference's Real (src/take.h:27); images at rounding level of the pinned oracle",
+                                      "f32": "f32 production arithmetic (see parity)",
+                                      "mixed": f"mixed: rounds 0..{(args.exact_bounces or 3) - 1} of every path (camera ray + next bounces) in f64 on "
+                                               "the f64 scene, the rest on f32 records and the f32 scene; images f64 (see parity: "
+                                               "within the tolerance of the all-f64 image of this workload)"}[args.precision],
                        "parallelism": f"tile-row strips over {world} GPU(s), scene replicated, one gather",
                        "bvh": {"builder": args.builder, "nodes": stats["n_nodes"], "prims": stats["n_prims"], "depth": stats["depth"],
                                "scene_bytes": stats["device_bytes"]},
@@ -359,27 +368,35 @@ def main():
         if world > 1:
             line["multi_gpu"] = main_leg["multi_gpu"]
         if world == 1 and args.alt_steps > 0:
-            # the same workload on the other arithmetic (own scene, own warm-up), and the two legs' images against each other
-            alt_prec = "f32" if args.precision == "f64" else "f64"
-            alt = run_leg(args, sd, alt_prec, args.alt_steps, 0, rank, world, backend, spp_total, False)
-            a64 = main_leg["image64"], alt["image64"]
-            d = (a64[0] - a64[1]).abs().amax(dim=2)
-            ref_img = a64[0] if args.precision == "f64" else a64[1]
-            line["parity"] = {"f32_vs_f64_rmse": float(((a64[0] - a64[1]) ** 2).mean().sqrt()), "spp": args.spp, "seed": 0,
-                              "pixels_within_1e-3": float((d < 1e-3).double().mean()),
-                              "mean_rel_diff": float(((a64[0].mean() - a64[1].mean()) / ref_img.mean()).abs()),
-                              "note": "per-pixel RMSE between the images of the timed f32 and f64 steps (same workload, matched "
-                                      "counter seeds); the f64 device path agrees with the pinned oracle at rounding level "
-                                      "(tests/test_gpu_parity.py), so this is the f32 path's distance from the reference's "
-                                      "arithmetic; f32 bounds per golden scene: tests/test_gpu_precision.py"}
-            leg = {"dtype": alt_prec, "value": alt["value"], "unit": "Msamples/s", "steps": alt["steps"],
-                   "ms_per_step": alt["elapsed"] / alt["steps"] * 1e3, "setup_s": alt["setup_s"],
-                   "kernel_ms": {k: alt["acc"][k] for k in KERNEL_MS},
-                   "roofline": roofline_of(args, alt_prec, alt["bytes_per_ray"], alt["acc"], alt["node_bytes"])}
-            if alt_prec == "f32":
-                leg["note"] = ("faster, but its image is f32_vs_f64_rmse away from the reference-precision image of this "
-                               "workload (north-star tolerance: 1e-3) — reported, not the headline")
-            line["production_f32" if alt_prec == "f32" else "reference_precision"] = leg
+            # the same workload on the other arithmetics (own scene, own warm-up), and every leg's image against the f64 one
+            images = {args.precision: main_leg["image64"]}
+            for alt_prec in [p for p in ("f64", "f32", "mixed") if p != args.precision and not (p == "mixed" and args.precision != "mixed")]:
+                alt = run_leg(args, sd, alt_prec, args.alt_steps, 0, rank, world, backend, spp_total, False)
+                images[alt_prec] = alt["image64"]
+                leg = {"dtype": alt_prec, "value": alt["value"], "unit": "Msamples/s", "steps": alt["steps"],
+                       "ms_per_step": alt["elapsed"] / alt["steps"] * 1e3, "setup_s": alt["setup_s"],
+                       "kernel_ms": {k: alt["acc"][k] for k in KERNEL_MS},
+                       "roofline": roofline_of(args, alt_prec, alt["bytes_per_ray"], alt["acc"], alt["node_bytes"])}
+                if alt_prec == "f32":
+                    leg["note"] = ("faster, but its image is parity.f32_vs_f64_rmse away from the reference-precision image of "
+                                   "this workload (north-star tolerance: 1e-3) — reported, not the headline")
+                line["production_f32" if alt_prec == "f32" else "reference_precision"] = leg
+            ref = images.get("f64")
+            if ref is not None:
+                par = {"spp": args.spp, "seed": 0, "tolerance": 1e-3,
+                       "note": "per-pixel RMSE between the images of the timed steps of each leg and the f64 leg's (same workload, "
+                               "matched counter seeds); the f64 device path agrees with the pinned oracle at rounding level "
+                               "(tests/test_gpu_parity.py), so these are distances from the reference's arithmetic"}
+                for name, im in images.items():
+                    if name == "f64" or im is None:
+                        continue
+                    d = (im - ref).abs().amax(dim=2)
+                    par[f"{name}_vs_f64_rmse"] = float(((im - ref) ** 2).mean().sqrt())
+                    par[f"{name}_pixels_within_1e-3"] = float((d < 1e-3).double().mean())
+                    par[f"{name}_mean_rel_diff"] = float(((im.mean() - ref.mean()) / ref.mean()).abs())
+                if args.precision != "f64":
+                    par["headline_within_tolerance"] = bool(par.get(f"{args.precision}_vs_f64_rmse", 1.0) < 1e-3)
+                line["parity"] = par
         if world == 1 and not args.no_cpu_baseline and not args.instanced:
             try:
                 line["cpu_baseline"] = cpu_baseline(args, sd)

@@ -117,7 +117,7 @@ class Scene:
         real lobes (tags 12..16, an extension — DESIGN.md §4d)"""
         self.sd = scene_data
         self.precision = precision
-        self.dtype = np.float64 if precision == D.TAKE_PRECISION_F64 else np.float32
+        self.dtype = np.float32 if precision == D.TAKE_PRECISION_F32 else np.float64
         desc, keep = scene_data.to_desc()
         opts = D.TakeBuildOpts(precision, bvh_threads, max_leaf_size, builder, 1 if burley_lobes else 0, 0)
         h = C.c_void_p()
@@ -138,6 +138,7 @@ class Scene:
 
     def _opts(self, spp, max_depth, seed, ray_epsilon, strip_first, strip_stride, samples_per_batch, integrator=0):
         o = D.TakeRenderOpts()
+        o.exact_bounces = int(getattr(self, "exact_bounces", 0))  # TAKE_PRECISION_MIXED scenes (0 = the library's default)
         o.spp, o.max_depth, o.seed, o.ray_epsilon = int(spp), int(max_depth), int(seed), float(ray_epsilon)
         o.strip_first, o.strip_stride, o.samples_per_batch = int(strip_first), int(strip_stride), int(samples_per_batch)
         o.integrator = int(integrator)
@@ -187,7 +188,7 @@ class Scene:
         """rays_abi: (n,8) array in TakeRayF/D layout (org3 tmin dir3 tmax) -> structured hits"""
         rays = np.ascontiguousarray(rays_abi, self.dtype)
         n = rays.shape[0]
-        if self.precision == D.TAKE_PRECISION_F64:
+        if self.precision != D.TAKE_PRECISION_F32:
             hits = np.zeros(n, dtype=[("shape_id", "<i4"), ("reserved", "<i4"), ("t", "<f8"), ("u", "<f8"), ("v", "<f8")])
         else:
             hits = np.zeros(n, dtype=[("shape_id", "<i4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
@@ -227,7 +228,7 @@ class SceneGroup:
                  builder=D.TAKE_BUILDER_AUTO, burley_lobes=False):
         self.sd = scene_data
         self.precision = precision
-        self.dtype = np.float64 if precision == D.TAKE_PRECISION_F64 else np.float32
+        self.dtype = np.float32 if precision == D.TAKE_PRECISION_F32 else np.float64
         desc, keep = scene_data.to_desc()
         opts = D.TakeBuildOpts(precision, bvh_threads, max_leaf_size, builder, 1 if burley_lobes else 0, 0)
         devs = (C.c_int32 * len(devices))(*devices)

@@ -7,6 +7,7 @@ c_float3 = C.c_float * 3
 
 TAKE_PRECISION_F32 = 0
 TAKE_PRECISION_F64 = 1
+TAKE_PRECISION_MIXED = 2  # first exact_bounces rounds in f64, the rest in f32; records and images are f64
 TAKE_OK, TAKE_E_INVALID, TAKE_E_DEVICE, TAKE_E_NO_GPU, TAKE_E_NOMEM = 0, -1, -2, -3, -4
 
 MAT_DIFFUSE, MAT_MIRROR, MAT_PLASTIC, MAT_PHONG, MAT_BLINN_PHONG, MAT_BLINN_PHONG_MICROFACET = range(6)
@@ -78,7 +79,7 @@ TAKE_BUILDER_HOST_SAH = 2
 class TakeRenderOpts(C.Structure):
     _fields_ = [("spp", C.c_int32), ("max_depth", C.c_int32), ("seed", C.c_uint64), ("ray_epsilon", C.c_double),
                 ("strip_first", C.c_int32), ("strip_stride", C.c_int32), ("samples_per_batch", C.c_int32),
-                ("integrator", C.c_int32)]
+                ("integrator", C.c_int32), ("exact_bounces", C.c_int32), ("reserved", C.c_int32)]
 
 
 # TakeRenderOpts.integrator: the reference's integrators (src/integrator/path_tracing.h:5, :114, :161, :274)

@@ -210,6 +210,9 @@ struct TakeScene {
 
 namespace {
 
+// records, images and trace hooks of a mixed-precision scene are the f64 ones (its f32 side finishes the paths)
+inline bool is_f64(const TakeScene *s) { return s->precision != TAKE_PRECISION_F32; }
+
 template <class R> SceneT<R> &pick(TakeScene *s);
 template <> SceneT<float> &pick<float>(TakeScene *s) { return s->f; }
 template <> SceneT<double> &pick<double>(TakeScene *s) { return s->d; }
@@ -698,6 +701,76 @@ template <class R> void dump_slot(const PathState<R> &st, int64_t slot, const ch
     std::fprintf(stderr, "\n");
 }
 
+// The shared buffers of a render's rounds: queues, queue words, sort scratch, counters.  They belong to the scene whose
+// precision owns the workspace (mixed-precision renders: the f64 scene's; the f32 rounds use them too — slot numbers
+// and queue words do not depend on the precision of the records they point to).
+struct RoundWs {
+    int32_t *q;  // queue words + tag counts
+    int32_t *queue[2], *shadow_queue, *sorted_queue;
+    uint8_t *sort_keys;
+    int32_t *sort_hist, *sort_base;
+    unsigned long long *counters;
+    int wide_grid;
+};
+// One round k of a batch on the records of precision RR: closest hits of the extend queue, material sort, shade,
+// shadow rays.  (Everything is enqueued; nothing waits.)
+template <class RR>
+void launch_round(TakeScene *ts, SceneT<RR> &sc, const RoundWs &ws, PathState<RR> st, const RenderParams<RR> &rp, int k, int64_t n_bound,
+                  Timer &tm, bool counting, bool sort_materials, hipStream_t stream, int64_t dump, int64_t slots) {
+    int32_t *q = ws.q;
+    int32_t *tag_count = q + Q_NUM_WORDS;
+    const int cur = k & 1, next = cur ^ 1;
+    int32_t *n_cur = q + (cur ? Q_N_EXT1 : Q_N_EXT0), *n_next = q + (next ? Q_N_EXT1 : Q_N_EXT0);
+    StackSpill spill{sc.spill.p, sc.spill_stride};
+    const PathIo<RR> io_ext{sc.dev.prims, st, ws.queue[cur], rp.ray_eps}, io_shadow{sc.dev.prims, st, ws.shadow_queue, rp.ray_eps};
+    // persistent trace grid, cut down when the queue (bounded by n_bound) cannot fill it: one block per 128 rays
+    const dim3 tgrid((unsigned)std::max<int64_t>(1, std::min<int64_t>(sc.trace_grid, (n_bound + 127) / 128)));
+    hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, stream, q, next);
+    tm.begin(TK_CLOSEST);
+    launch_trace<RR>(sc.group, false, counting, tgrid, stream, sc.dev, io_ext, n_cur, 0, q + Q_HEAD_CLOSEST, ws.counters,
+                     (int)C_RAYS_CLOSEST, spill);
+    tm.end();
+    if (dump >= 0 && dump < slots) dump_slot(st, dump, "after trace_closest", k, stream);
+    const int32_t *shade_in = ws.queue[cur];
+    if (sort_materials) {
+        tm.begin(TK_OTHER);
+        // every wave of the sort gets >= 512 entries of the (bounded) queue: the one-block scan walks
+        // 13 x waves counters, which must not dominate small rounds (it was 40 % of a 256x256 render)
+        const int sort_grid = (int)std::max<int64_t>(1, std::min<int64_t>(ws.wide_grid, (n_bound + 2047) / 2048));
+        hipLaunchKernelGGL((k_sort_count<RR>), dim3(sort_grid), dim3(BLOCK), 0, stream, sc.dev.prims, sc.dev.inst_shade, st,
+                           ws.queue[cur], n_cur, ws.sort_keys, ws.sort_hist);
+        hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(SORT_SCAN_THREADS), 0, stream, ws.sort_hist, ws.sort_base, tag_count,
+                           sort_grid * (BLOCK / WAVE));
+        hipLaunchKernelGGL(k_sort_scatter, dim3(sort_grid), dim3(BLOCK), 0, stream, ws.queue[cur], n_cur, ws.sort_keys, ws.sort_base,
+                           ws.sorted_queue);
+        tm.end();
+        shade_in = ws.sorted_queue;
+    }
+    tm.begin(TK_SHADE);
+    {
+        const int shade_grid = (int)((n_bound + BLOCK - 1) / BLOCK);
+        ShadeArgs<RR> sa{sc.dev, rp, st, shade_in, n_cur, sort_materials ? tag_count : nullptr, ws.queue[next],
+                         n_next, ws.shadow_queue, q + Q_N_SHADOW, k, ws.counters, shade_grid, stream};
+        if (sort_materials) {
+            // one specialised launch per material tag present in the scene + the miss segment
+            for (int t = 0; t < TAKE_MAT_COUNT; t++)
+                if (sc.host.tag_mask & (1u << t)) launch_shade<RR>(t, sa);
+            launch_shade<RR>(TAG_MISS, sa);
+        } else {
+            launch_shade<RR>(sc.host.single_tag, sa);
+        }
+    }
+    tm.end();
+    if (dump >= 0 && dump < slots) dump_slot(st, dump, "after shade", k, stream);
+    if (k <= rp.max_depth && rp.integrator == 0) {  // integrators 1..3 trace no shadow rays
+        tm.begin(TK_SHADOW);
+        launch_trace<RR>(sc.group, true, counting, tgrid, stream, sc.dev, io_shadow, q + Q_N_SHADOW, 0, q + Q_HEAD_SHADOW, ws.counters,
+                         (int)C_RAYS_SHADOW, spill);
+        tm.end();
+        if (dump >= 0 && dump < slots) dump_slot(st, dump, "after trace_shadow", k, stream);
+    }
+}
+
 // first_sample / keep_accum: progressive rendering — the samples of this call are numbered from first_sample (their
 // random streams are those of a one-shot render's samples first_sample .. first_sample + spp - 1), keep_accum adds them
 // to what `accum` holds instead of starting from zero, and the image is the mean over first_sample + spp samples.
@@ -719,6 +792,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     ts->counters = TakeCounters{};
     ts->counters.node_bytes = sc.dev.qnodes8 ? sizeof(QNode8) : (sc.dev.qnodes ? sizeof(QNode4) : sizeof(Node4<R>));
     ts->counters.prim_bytes = PRIM_TEST_BYTES * (int)(sizeof(R) / 4);
+    if (ts->precision == TAKE_PRECISION_MIXED) ts->counters.prim_bytes = PRIM_TEST_BYTES;  // (most rounds read the f32 records)
     if (npix == 0) return TAKE_OK;
     if (npix >= ((int64_t)1 << 30)) return fail(TAKE_E_INVALID, "image too large");
 
@@ -729,7 +803,9 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     int64_t target = (int64_t)512 << 20;
     {
         size_t free_b = 0, total_b = 0;
-        const int64_t per_path = (int64_t)PATH_REC * (int64_t)sizeof(R) + 4 * (int64_t)sizeof(int32_t);
+        // (mixed precision: every slot has an f32 record beside its f64 one)
+        const int64_t per_path = (int64_t)PATH_REC * (int64_t)(sizeof(R) + (ts->precision == TAKE_PRECISION_MIXED ? sizeof(float) : 0)) +
+                                 4 * (int64_t)sizeof(int32_t);
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const int64_t have = (int64_t)sc.capacity * per_path;  // already allocated by an earlier render
             // (shards of a scene group that share a device size their batches concurrently: each takes its share)
@@ -759,14 +835,6 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     ts->timed.clear();
     Timer tm{ts, stream, timing};
     int32_t *q = sc.qwords.p;
-    int32_t *tag_count = q + Q_NUM_WORDS;
-    StackSpill spill{sc.spill.p, sc.spill_stride};
-    const PathIo<R> io_ext0{sc.dev.prims, st, sc.queue[0].p, rp.ray_eps}, io_ext1{sc.dev.prims, st, sc.queue[1].p, rp.ray_eps};
-    const PathIo<R> io_shadow{sc.dev.prims, st, sc.shadow_queue.p, rp.ray_eps};
-    // persistent trace grid, cut down when the queue (bounded by n_bound) cannot fill it: one block per 128 rays
-    auto trace_grid_for = [&](int64_t n_rays) {
-        return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(sc.trace_grid, (n_rays + 127) / 128)));
-    };
     const int wide_grid = (int)std::min<int64_t>((slots + BLOCK - 1) / BLOCK, (int64_t)ts->num_cus * 8);
     const int pix_grid = (int)std::min<int64_t>((npix + BLOCK - 1) / BLOCK, (int64_t)ts->num_cus * 8);
 
@@ -775,6 +843,30 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
         if (sc.sort_hist.n != need) {
             HIP_TRY(sc.sort_hist.alloc(need));
             HIP_TRY(sc.sort_base.alloc(need));
+        }
+    }
+    const RoundWs ws{q, {sc.queue[0].p, sc.queue[1].p}, sc.shadow_queue.p, sc.sorted_queue.p, sc.sort_keys.p, sc.sort_hist.p, sc.sort_base.p,
+                     sc.counters.p, wide_grid};
+    // mixed precision (TAKE_PRECISION_MIXED): rounds k < exact_rounds on the f64 records and scene, the rest on f32
+    // records of the same slots and the f32 scene
+    bool mixed = false;
+    int exact_rounds = 0;
+    PathState<float> st32{nullptr, 0};
+    RenderParams<float> rp32{};
+    if constexpr (sizeof(R) == 8) {
+        mixed = ts->precision == TAKE_PRECISION_MIXED;
+        if (mixed) {
+            exact_rounds = o.exact_bounces > 0 ? o.exact_bounces : TAKE_DEFAULT_EXACT_BOUNCES;
+            if (o.integrator != 0) return fail(TAKE_E_INVALID, "mixed precision renders the reference's path_tracing (integrator 0) only");
+            if ((int64_t)ts->f.state_r.n < (int64_t)PATH_REC * slots) {
+                if (ts->f.state_r.alloc((size_t)PATH_REC * slots) != hipSuccess)
+                    return fail(TAKE_E_NOMEM, "out of device memory for the f32 path records of a mixed-precision render");
+            }
+            st32 = PathState<float>{ts->f.state_r.p, slots};
+            rp32.width = rp.width, rp32.height = rp.height, rp32.n_local_rows = rp.n_local_rows, rp32.npix = rp.npix;
+            rp32.strip_first = rp.strip_first, rp32.strip_stride = rp.strip_stride, rp32.spp = rp.spp, rp32.max_depth = rp.max_depth;
+            rp32.integrator = rp.integrator, rp32.seed = rp.seed;
+            rp32.ray_eps = o.ray_epsilon > 0 ? (float)o.ray_epsilon : 1e-4f;
         }
     }
     if (!keep_accum) HIP_TRY(hipMemsetAsync(sc.accum.p, 0, sizeof(R) * 3 * npix, stream));
@@ -792,6 +884,8 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
         const int64_t n = (int64_t)nb * npix;
         rp.s0 = (int32_t)first_sample + s0;
         rp.spb = nb;
+        rp32.s0 = rp.s0, rp32.spb = nb;
+        if (mixed) HIP_TRY(hipMemsetAsync(ts->f.state_r.p, 0, sizeof(float) * (size_t)PATH_REC * (size_t)n, stream));
         tm.begin(TK_OTHER);
         hipLaunchKernelGGL((k_generate<R>), dim3(wide_grid), dim3(BLOCK), 0, stream, sc.dev, rp, st, sc.queue[0].p, n);
         hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, stream, q, (int)Q_N_EXT0, (int32_t)n);
@@ -799,52 +893,20 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
         const int rounds = o.max_depth + 2;
         int64_t n_bound = n;  // upper bound of the extend-queue length (queues only shrink)
         for (int k = 0; k < rounds; k++) {
-            const int cur = k & 1, next = cur ^ 1;
-            int32_t *n_cur = q + (cur ? Q_N_EXT1 : Q_N_EXT0), *n_next = q + (next ? Q_N_EXT1 : Q_N_EXT0);
-            hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, stream, q, next);
-            tm.begin(TK_CLOSEST);
-            const dim3 tgrid = trace_grid_for(n_bound);
-            launch_trace<R>(sc.group, false, counting, tgrid, stream, sc.dev, cur ? io_ext1 : io_ext0, n_cur, 0,
-                            q + Q_HEAD_CLOSEST, sc.counters.p, (int)C_RAYS_CLOSEST, spill);
-            tm.end();
-            if (dump >= 0 && dump < slots) dump_slot(st, dump, "after trace_closest", k, stream);
-            const int32_t *shade_in = sc.queue[cur].p;
-            if (sort_materials) {
-                tm.begin(TK_OTHER);
-                // every wave of the sort gets >= 512 entries of the (bounded) queue: the one-block scan walks
-                // 13 x waves counters, which must not dominate small rounds (it was 40 % of a 256x256 render)
-                const int sort_grid = (int)std::max<int64_t>(1, std::min<int64_t>(wide_grid, (n_bound + 2047) / 2048));
-                hipLaunchKernelGGL((k_sort_count<R>), dim3(sort_grid), dim3(BLOCK), 0, stream, sc.dev.prims, sc.dev.inst_shade, st,
-                                   sc.queue[cur].p, n_cur, sc.sort_keys.p, sc.sort_hist.p);
-                hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(SORT_SCAN_THREADS), 0, stream, sc.sort_hist.p,
-                                   sc.sort_base.p, tag_count, sort_grid * (BLOCK / WAVE));
-                hipLaunchKernelGGL(k_sort_scatter, dim3(sort_grid), dim3(BLOCK), 0, stream, sc.queue[cur].p, n_cur,
-                                   sc.sort_keys.p, sc.sort_base.p, sc.sorted_queue.p);
-                tm.end();
-                shade_in = sc.sorted_queue.p;
-            }
-            tm.begin(TK_SHADE);
-            {
-                const int shade_grid = (int)((n_bound + BLOCK - 1) / BLOCK);
-                ShadeArgs<R> sa{sc.dev, rp, st, shade_in, n_cur, sort_materials ? tag_count : nullptr, sc.queue[next].p,
-                                n_next, sc.shadow_queue.p, q + Q_N_SHADOW, k, sc.counters.p, shade_grid, stream};
-                if (sort_materials) {
-                    // one specialised launch per material tag present in the scene + the miss segment
-                    for (int t = 0; t < TAKE_MAT_COUNT; t++)
-                        if (sc.host.tag_mask & (1u << t)) launch_shade<R>(t, sa);
-                    launch_shade<R>(TAG_MISS, sa);
-                } else {
-                    launch_shade<R>(sc.host.single_tag, sa);
+            const int next = (k & 1) ^ 1;
+            int32_t *n_next = q + (next ? Q_N_EXT1 : Q_N_EXT0);
+            if constexpr (sizeof(R) == 8) {
+                if (mixed && k == exact_rounds) {
+                    // mixed precision: the paths still alive continue on f32 records (and the f32 scene) from here on
+                    tm.begin(TK_OTHER);
+                    hipLaunchKernelGGL(k_convert_state, dim3(wide_grid), dim3(BLOCK), 0, stream, st, st32, ws.queue[k & 1],
+                                       q + ((k & 1) ? Q_N_EXT1 : Q_N_EXT0));
+                    tm.end();
                 }
-            }
-            tm.end();
-            if (dump >= 0 && dump < slots) dump_slot(st, dump, "after shade", k, stream);
-            if (k <= o.max_depth && o.integrator == 0) {  // integrators 1..3 trace no shadow rays
-                tm.begin(TK_SHADOW);
-                launch_trace<R>(sc.group, true, counting, tgrid, stream, sc.dev, io_shadow, q + Q_N_SHADOW, 0,
-                                q + Q_HEAD_SHADOW, sc.counters.p, (int)C_RAYS_SHADOW, spill);
-                tm.end();
-                if (dump >= 0 && dump < slots) dump_slot(st, dump, "after trace_shadow", k, stream);
+                if (mixed && k >= exact_rounds) launch_round<float>(ts, ts->f, ws, st32, rp32, k, n_bound, tm, counting, sort_materials, stream, -1, slots);
+                else launch_round<R>(ts, sc, ws, st, rp, k, n_bound, tm, counting, sort_materials, stream, dump, slots);
+            } else {
+                launch_round<R>(ts, sc, ws, st, rp, k, n_bound, tm, counting, sort_materials, stream, dump, slots);
             }
             // Queue length of the next round, read back asynchronously (pinned word + event, polled — the launch loop
             // never waits for the GPU): any value that has arrived bounds the grids of all later rounds (queues only
@@ -878,7 +940,12 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
         // (outstanding read-backs of this batch complete with the stream; the ring indices just move on)
         poll_done = poll_issued;
         tm.begin(TK_OTHER);
-        hipLaunchKernelGGL((k_accumulate<R>), dim3(pix_grid), dim3(BLOCK), 0, stream, st, sc.accum.p, (int32_t)npix, nb);
+        if constexpr (sizeof(R) == 8) {
+            if (mixed) hipLaunchKernelGGL(k_accumulate_mixed, dim3(pix_grid), dim3(BLOCK), 0, stream, st, st32, sc.accum.p, (int32_t)npix, nb);
+            else hipLaunchKernelGGL((k_accumulate<R>), dim3(pix_grid), dim3(BLOCK), 0, stream, st, sc.accum.p, (int32_t)npix, nb);
+        } else {
+            hipLaunchKernelGGL((k_accumulate<R>), dim3(pix_grid), dim3(BLOCK), 0, stream, st, sc.accum.p, (int32_t)npix, nb);
+        }
         tm.end();
     }
     tm.begin(TK_OTHER);
@@ -1030,8 +1097,10 @@ int take_hip_scene_create(const TakeSceneDesc *desc, const TakeBuildOpts *opts, 
     if (nd < 0) return nd;
     TakeBuildOpts o{};
     if (opts) o = *opts;
-    if (o.precision != TAKE_PRECISION_F32 && o.precision != TAKE_PRECISION_F64)
+    if (o.precision != TAKE_PRECISION_F32 && o.precision != TAKE_PRECISION_F64 && o.precision != TAKE_PRECISION_MIXED)
         return fail(TAKE_E_INVALID, "unknown precision");
+    if (o.precision == TAKE_PRECISION_MIXED && desc->n_instances > 0)
+        return fail(TAKE_E_INVALID, "mixed precision: one-level scenes only");
     if (o.builder < TAKE_BUILDER_AUTO || o.builder > TAKE_BUILDER_HOST_SAH) return fail(TAKE_E_INVALID, "unknown builder");
     TakeScene *ts = new (std::nothrow) TakeScene();
     if (!ts) return fail(TAKE_E_NOMEM, "out of host memory");
@@ -1044,7 +1113,8 @@ int take_hip_scene_create(const TakeSceneDesc *desc, const TakeBuildOpts *opts, 
     ts->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int rc;
     try {
-        rc = o.precision == TAKE_PRECISION_F64 ? upload_scene<double>(ts, *desc, o) : upload_scene<float>(ts, *desc, o);
+        rc = o.precision != TAKE_PRECISION_F32 ? upload_scene<double>(ts, *desc, o) : upload_scene<float>(ts, *desc, o);
+        if (!rc && o.precision == TAKE_PRECISION_MIXED) rc = upload_scene<float>(ts, *desc, o);  // the same scene in f32 beside it
     } catch (const std::bad_alloc &) {
         rc = fail(TAKE_E_NOMEM, "out of host memory while preparing the scene");
     } catch (const std::exception &e) {
@@ -1079,14 +1149,14 @@ int take_hip_render_rows(const TakeScene *ts, int32_t strip_first, int32_t strip
     if (!ts) return fail(TAKE_E_INVALID, "null scene");
     if (strip_stride <= 0 || strip_first < 0 || strip_first >= strip_stride)
         return fail(TAKE_E_INVALID, "strip_first must be in [0, strip_stride)");
-    const int H = ts->precision == TAKE_PRECISION_F64 ? ts->d.host.cam.height : ts->f.host.cam.height;
+    const int H = is_f64(ts) ? ts->d.host.cam.height : ts->f.host.cam.height;
     return rows_of(H, strip_first, strip_stride, rows_out);
 }
 
 int take_hip_render_device(TakeScene *ts, const TakeRenderOpts *opts, void *d_rgb_out, void *stream) {
     if (!ts || !opts || !d_rgb_out) return fail(TAKE_E_INVALID, "null argument");
     TAKE_ON_DEVICE(ts);
-    if (ts->precision == TAKE_PRECISION_F64) return render_impl<double>(ts, *opts, d_rgb_out, (hipStream_t)stream);
+    if (is_f64(ts)) return render_impl<double>(ts, *opts, d_rgb_out, (hipStream_t)stream);
     return render_impl<float>(ts, *opts, d_rgb_out, (hipStream_t)stream);
 }
 
@@ -1094,7 +1164,7 @@ int take_hip_render_device(TakeScene *ts, const TakeRenderOpts *opts, void *d_rg
 int take_hip_render_accumulate(TakeScene *ts, const TakeRenderOpts *opts, int32_t restart, void *d_rgb_out, void *stream) {
     if (!ts || !opts || !d_rgb_out) return fail(TAKE_E_INVALID, "null argument");
     TAKE_ON_DEVICE(ts);
-    const bool f64 = ts->precision == TAKE_PRECISION_F64;
+    const bool f64 = is_f64(ts);
     const TakeRenderOpts &a = ts->acc_opts;
     const bool fresh = restart != 0 || ts->acc_samples == 0;
     if (!fresh && (a.seed != opts->seed || a.max_depth != opts->max_depth || a.integrator != opts->integrator ||
@@ -1120,7 +1190,7 @@ int64_t take_hip_accumulated_samples(const TakeScene *ts) { return ts ? ts->acc_
 int take_hip_render(TakeScene *ts, const TakeRenderOpts *opts, void *rgb_out_host) {
     if (!ts || !opts || !rgb_out_host) return fail(TAKE_E_INVALID, "null argument");
     TAKE_ON_DEVICE(ts);
-    const bool f64 = ts->precision == TAKE_PRECISION_F64;
+    const bool f64 = is_f64(ts);
     const int W = f64 ? ts->d.host.cam.width : ts->f.host.cam.width;
     const int stride = opts->strip_stride > 0 ? opts->strip_stride : 1;
     if (opts->strip_first < 0 || opts->strip_first >= stride)
@@ -1162,7 +1232,7 @@ int take_hip_pack_exr_scanlines(const void *d_rgb, int32_t precision, int32_t wi
 int take_hip_render_exr_scanlines(TakeScene *ts, const TakeRenderOpts *opts, uint16_t *out_host) {
     if (!ts || !opts || !out_host) return fail(TAKE_E_INVALID, "null argument");
     TAKE_ON_DEVICE(ts);
-    const bool f64 = ts->precision == TAKE_PRECISION_F64;
+    const bool f64 = is_f64(ts);
     const int W = f64 ? ts->d.host.cam.width : ts->f.host.cam.width, H = f64 ? ts->d.host.cam.height : ts->f.host.cam.height;
     TakeRenderOpts o = *opts;
     o.strip_first = 0, o.strip_stride = 1;
@@ -1183,13 +1253,13 @@ int take_hip_render_exr_scanlines(TakeScene *ts, const TakeRenderOpts *opts, uin
 int take_hip_trace_closest(TakeScene *ts, const void *rays, int64_t n, void *hits) {
     if (!ts || (n > 0 && (!rays || !hits))) return fail(TAKE_E_INVALID, "null argument");
     TAKE_ON_DEVICE(ts);
-    return ts->precision == TAKE_PRECISION_F64 ? trace_host<double>(ts, rays, n, hits, nullptr, false)
+    return is_f64(ts) ? trace_host<double>(ts, rays, n, hits, nullptr, false)
                                                : trace_host<float>(ts, rays, n, hits, nullptr, false);
 }
 int take_hip_trace_any(TakeScene *ts, const void *rays, int64_t n, int32_t *occluded) {
     if (!ts || (n > 0 && (!rays || !occluded))) return fail(TAKE_E_INVALID, "null argument");
     TAKE_ON_DEVICE(ts);
-    return ts->precision == TAKE_PRECISION_F64 ? trace_host<double>(ts, rays, n, nullptr, occluded, true)
+    return is_f64(ts) ? trace_host<double>(ts, rays, n, nullptr, occluded, true)
                                                : trace_host<float>(ts, rays, n, nullptr, occluded, true);
 }
 int take_hip_trace_closest_device(TakeScene *ts, const void *d_rays, int64_t n, void *d_hits, int32_t count_mode,
@@ -1197,7 +1267,7 @@ int take_hip_trace_closest_device(TakeScene *ts, const void *d_rays, int64_t n, 
     if (!ts || (n > 0 && (!d_rays || !d_hits))) return fail(TAKE_E_INVALID, "null argument");
     if (n == 0) return TAKE_OK;
     TAKE_ON_DEVICE(ts);
-    return ts->precision == TAKE_PRECISION_F64
+    return is_f64(ts)
                ? trace_impl<double>(ts, d_rays, n, d_hits, nullptr, false, count_mode != 0, (hipStream_t)stream)
                : trace_impl<float>(ts, d_rays, n, d_hits, nullptr, false, count_mode != 0, (hipStream_t)stream);
 }
@@ -1318,8 +1388,9 @@ int replicate_scene(const TakeScene *src, int device, TakeScene **out) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ts->num_cus = cus;
         (void)hipGetLastError();
     }
-    if (!rc) rc = src->precision == TAKE_PRECISION_F64 ? replicate_t(src->d, src->device, src->num_cus, ts->d, device, ts->num_cus)
-                                                       : replicate_t(src->f, src->device, src->num_cus, ts->f, device, ts->num_cus);
+    if (!rc) rc = is_f64(src) ? replicate_t(src->d, src->device, src->num_cus, ts->d, device, ts->num_cus)
+                              : replicate_t(src->f, src->device, src->num_cus, ts->f, device, ts->num_cus);
+    if (!rc && src->precision == TAKE_PRECISION_MIXED) rc = replicate_t(src->f, src->device, src->num_cus, ts->f, device, ts->num_cus);
     if (rc) {
         ts->f.release(), ts->d.release();
         delete ts;
@@ -1452,7 +1523,7 @@ int take_hip_group_create(const TakeSceneDesc *desc, const TakeBuildOpts *opts, 
             x->mem_share = share;
         }
         TakeScene *t0 = g->scenes[0];
-        g->f64 = t0->precision == TAKE_PRECISION_F64;
+        g->f64 = is_f64(t0);
         g->width = g->f64 ? t0->d.host.cam.width : t0->f.host.cam.width;
         g->height = g->f64 ? t0->d.host.cam.height : t0->f.host.cam.height;
         const size_t esz = g->f64 ? 8 : 4;
@@ -1531,12 +1602,12 @@ int take_hip_set_instrumentation(TakeScene *ts, int32_t flags) {
 int take_hip_scene_stats(const TakeScene *ts, int64_t *n_nodes, int64_t *n_prims, int32_t *depth,
                          int64_t *device_bytes) {
     if (!ts) return fail(TAKE_E_INVALID, "null scene");
-    const bool f64 = ts->precision == TAKE_PRECISION_F64;
+    const bool f64 = is_f64(ts);
     const WideBvhStats &s = f64 ? ts->d.host.stats : ts->f.host.stats;
     if (n_nodes) *n_nodes = s.n_nodes;
     if (n_prims) *n_prims = s.n_prims;
     if (depth) *depth = s.depth;
-    if (device_bytes) *device_bytes = (int64_t)(f64 ? ts->d.scene_bytes() : ts->f.scene_bytes());
+    if (device_bytes) *device_bytes = (int64_t)((f64 ? ts->d.scene_bytes() : 0) + (ts->precision != TAKE_PRECISION_F64 ? ts->f.scene_bytes() : 0));
     return TAKE_OK;
 }
 

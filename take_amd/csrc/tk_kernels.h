@@ -306,6 +306,38 @@ k_accumulate(PathState<R> st, R *accum, int32_t npix, int32_t spb) {
         accum[3 * (int64_t)p + 2] = b;
     }
 }
+// Mixed precision (TAKE_PRECISION_MIXED): the paths of `queue` (alive after the exact rounds) continue on f32 records
+// of the same slots: ray, throughput, radiance so far, pending BSDF sample, random-stream counter, flags.  The radiance
+// moves with the path (the f64 record's is cleared), so that a sample's value is the sum of the two records' radiance
+// whichever round its path ended in (k_accumulate_mixed; the f32 records' radiance words are zeroed per batch).
+__global__ void __launch_bounds__(BLOCK)
+k_convert_state(PathState<double> a, PathState<float> b, const int32_t *__restrict__ queue, const int32_t *__restrict__ n_ptr) {
+    const int32_t n = *n_ptr;
+    for (int32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const int64_t s = queue[i];
+        constexpr int WORDS[] = {S_OX, S_OY, S_OZ, S_DX, S_DY, S_DZ, S_PDF, S_TX, S_TY, S_TZ, S_LX, S_LY, S_LZ, S_FX, S_FY, S_FZ};
+#pragma unroll
+        for (int w = 0; w < 16; w++) b.R_(WORDS[w], s) = (float)a.R_(WORDS[w], s);
+        b.I_(S_CTR, s) = a.I_(S_CTR, s);
+        b.I_(S_FLAGS, s) = a.I_(S_FLAGS, s);
+        a.R_(S_LX, s) = 0.0, a.R_(S_LY, s) = 0.0, a.R_(S_LZ, s) = 0.0;
+    }
+}
+__global__ void __launch_bounds__(BLOCK)
+k_accumulate_mixed(PathState<double> a, PathState<float> b, double *accum, int32_t npix, int32_t spb) {
+    for (int32_t p = blockIdx.x * BLOCK + threadIdx.x; p < npix; p += gridDim.x * BLOCK) {
+        double r = accum[3 * (int64_t)p], g = accum[3 * (int64_t)p + 1], bl = accum[3 * (int64_t)p + 2];
+        for (int s = 0; s < spb; s++) {
+            const int64_t slot = (int64_t)s * npix + p;
+            r = r + (a.R_(S_LX, slot) + (double)b.R_(S_LX, slot));
+            g = g + (a.R_(S_LY, slot) + (double)b.R_(S_LY, slot));
+            bl = bl + (a.R_(S_LZ, slot) + (double)b.R_(S_LZ, slot));
+        }
+        accum[3 * (int64_t)p] = r;
+        accum[3 * (int64_t)p + 1] = g;
+        accum[3 * (int64_t)p + 2] = bl;
+    }
+}
 // src/render.cpp:78: img(x, height - y - 1) = color / spp — the local rows come out in increasing image row.
 template <class R>
 __global__ void __launch_bounds__(BLOCK)

@@ -67,9 +67,11 @@ Image3 render(const std::vector<std::string> &params) {
     take_hip::FlatScene flat;  // owns the small tables; mesh arrays are referenced in place
     take_hip::flatten_scene(scene, flat);
     const char *prec = std::getenv("TAKE_HIP_PRECISION");
-    const bool f64 = prec && std::string(prec) == "f64";
+    // TAKE_HIP_PRECISION: f32 (default) | f64 (the reference's Real) | mixed (first bounces f64, the rest f32; images double)
+    const bool mixed = prec && std::string(prec) == "mixed";
+    const bool f64 = mixed || (prec && std::string(prec) == "f64");
     TakeBuildOpts bo{};
-    bo.precision = f64 ? TAKE_PRECISION_F64 : TAKE_PRECISION_F32;
+    bo.precision = mixed ? TAKE_PRECISION_MIXED : (f64 ? TAKE_PRECISION_F64 : TAKE_PRECISION_F32);
     // TAKE_HIP_BURLEY=1: the scene's disney* materials get real lobes instead of upstream's Lambert clones (extension)
     if (const char *b = std::getenv("TAKE_HIP_BURLEY")) bo.burley_lobes = std::atoi(b) != 0;
     // TAKE_HIP_GPUS: "<n>" or "<n>:<device>" (all shards on one device)

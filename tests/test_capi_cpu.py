@@ -37,7 +37,7 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.take_hip_abi_version() == 3
+    assert lib.take_hip_abi_version() == 4
 
 
 def test_struct_layout_matches_header():

@@ -247,3 +247,19 @@ def test_gpu_instance_coincident_with_plain_geometry_tie_rule(precision):
         assert centre[2] > centre[0]  # the quad renders in the placement's blue, not the coincident red
     finally:
         sc.close()
+
+
+@pytest.mark.parametrize("braid", [4, 16])
+def test_host_braided_placements_equal_flattened(braid, monkeypatch):
+    """TAKE_HIP_BRAID > 1: a placement enters the top-level tree as several entries (subtrees of the prototype's tree,
+    each with its own instance record and root) — same hits, same shape ids"""
+    monkeypatch.setenv("TAKE_HIP_BRAID", str(braid))
+    sd = small(n_inst=30, tris=300)
+    fl = sd.flattened()
+    rays = random_rays(6000, 11, tmin=1e-7)
+    a = hostsim_trace(sd, 1, rays).astype(np.float64)
+    monkeypatch.delenv("TAKE_HIP_BRAID")
+    b = hostsim_trace(fl, 1, rays).astype(np.float64)
+    assert np.array_equal(a[:, 0], b[:, 0])
+    hit = a[:, 0] >= 0
+    assert hit.sum() > 2500 and np.abs(a[hit, 1] - b[hit, 1]).max() < 1e-13
