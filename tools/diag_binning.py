@@ -58,7 +58,7 @@ def run(order, label):
 
 
 base = run(np.arange(n), "random order")
-for bits in (2, 3, 4, 5, 7):
+for bits in (1, 2, 3, 4):
     t0 = time.time()
     order = np.argsort(morton(org, bits), kind="stable")
     run(order, f"sorted, {1 << bits}^3 cells")

@@ -10,9 +10,15 @@ out="$root/gpurun_out/prof_r03"
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
+# usage: tools/profile_r03.sh [default] [mixed] [f64] [f32] [summary]   (no arguments: everything; the whole set takes
+# ~15 minutes of GPU time, so it can be split over several gpurun calls — gpurun_out/ is merged back between them)
+what="${*:-default mixed f64 f32 summary}"
+if [[ " $what " == *" default "* ]]; then
 echo "--- plain run"; python3 "$root/bench.py" > "$out/bench_plain.log" 2>&1; tail -n 1 "$out/bench_plain.log" | cut -c1-300
 echo "--- stats"; rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 "$root/bench.py" > "$out/stats.log" 2>&1; tail -n 1 "$out/stats.log" | cut -c1-120
+fi
 for prec in mixed f64 f32; do
+  [[ " $what " == *" $prec "* ]] || continue
   pass() { local name="$1"; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/${prec}_$name" -- python3 "$root/bench.py" --precision $prec --alt-steps 0 --no-cpu-baseline > "$out/${prec}_$name.log" 2>&1; echo "pass $prec $name rc=$?"; }
   pass fetch FETCH_SIZE
   pass write WRITE_SIZE
@@ -21,7 +27,7 @@ for prec in mixed f64 f32; do
   pass sq2 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM
   pass grbm GRBM_GUI_ACTIVE
 done
+if [[ " $what " == *" summary "* ]]; then
 cd "$root" && python3 tools/profile_summary_r03.py "$out" > "$out/summary.txt" 2>&1
-# the raw per-dispatch CSVs are large: keep only the stats CSV and the summaries
-find "$out" -name "*counter_collection.csv" -delete; find "$out" -name "*kernel_trace.csv" -delete
 head -60 "$out/summary.txt"
+fi
