@@ -184,9 +184,13 @@ def roofline_of(args, precision, bytes_per_ray, acc, node_bytes):
     """`roofline` of the closest-hit kernel of one leg: achieved = algorithmic bytes per launch / average launch time
     (HIP events on the render stream, inside the timed region); the committed PMC passes add what reaches the fabric
     and how busy the vector ALUs are."""
-    n_launch = max(acc["launches_trace_closest"], 1)
-    avg_ms = acc["ms_trace_closest"] / n_launch
-    bytes_per_launch = bytes_per_ray * acc["rays_closest"] / n_launch
+    # (mixed precision: the dominant kernel is the f32 instance, which runs all rounds but the first three — its own
+    # launches, its own time, its own rays)
+    tail = precision == "mixed" and acc.get("launches_trace_closest_f32", 0) > 0
+    n_launch = max(acc["launches_trace_closest_f32" if tail else "launches_trace_closest"], 1)
+    avg_ms = acc["ms_trace_closest_f32" if tail else "ms_trace_closest"] / n_launch
+    rays_in = acc["rays_closest_f32" if tail else "rays_closest"]
+    bytes_per_launch = bytes_per_ray * rays_in / n_launch
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     pmc = measured_counters(args, precision)
     fabric = pmc["traffic"] / (avg_ms * 1e-3) / 1e9 if (pmc["traffic"] and avg_ms > 0) else None
@@ -205,7 +209,7 @@ def roofline_of(args, precision, bytes_per_ray, acc, node_bytes):
             "kernel": f"tk::k_trace_group<{rtype},1,false,false,PathIo<{rtype}>,true> (closest hit, one ray per lane, "
                       "64-byte compressed nodes)",
             "launches": n_launch, "avg_launch_ms": avg_ms, "bytes_per_ray": bytes_per_ray, "node_bytes": node_bytes,
-            "rays_per_launch": acc["rays_closest"] / n_launch}
+            "rays_per_launch": rays_in / n_launch}
 
 
 def run_leg(args, sd, precision, steps, warmup, rank, world, backend, spp_total, is_main):
@@ -257,7 +261,8 @@ def run_leg(args, sd, precision, steps, warmup, rank, world, backend, spp_total,
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     acc = {"ms_trace_closest": 0.0, "launches_trace_closest": 0, "rays_closest": 0, "rays_shadow": 0,
-           "ms_trace_shadow": 0.0, "ms_shade": 0.0, "ms_other": 0.0, "ms_total": 0.0, "bounces": 0}
+           "ms_trace_shadow": 0.0, "ms_shade": 0.0, "ms_other": 0.0, "ms_total": 0.0, "bounces": 0,
+           "rays_closest_f32": 0, "ms_trace_closest_f32": 0.0, "launches_trace_closest_f32": 0}
     img = None
     render_s = gather_s = 0.0
     for _ in range(steps):

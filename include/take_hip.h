@@ -287,6 +287,11 @@ typedef struct TakeCounters {
     uint64_t wave_node_steps;/* wave-level node-phase iterations (counting mode): node_visits / (16 * this) is
                                 the fraction of the 16 ray slots of a wave doing useful work in a node step */
     uint64_t wave_leaf_steps;/* wave-level leaf-phase iterations (counting mode)  */
+    /* mixed-precision renders: the share of rays_closest / ms_trace_closest / launches_trace_closest that belongs to the
+     * f32 rounds (the f32 instance of the closest-hit kernel); zero for f32 and f64 scenes */
+    uint64_t rays_closest_f32;
+    double ms_trace_closest_f32;
+    uint64_t launches_trace_closest_f32;
 } TakeCounters;
 
 const char *take_hip_last_error(void);

@@ -110,7 +110,8 @@ class TakeCounters(C.Structure):
                 ("ms_other", C.c_double), ("ms_total", C.c_double),
                 ("launches_trace_closest", C.c_uint64), ("launches_trace_shadow", C.c_uint64),
                 ("node_bytes", C.c_uint64), ("prim_bytes", C.c_uint64), ("leaf_visits", C.c_uint64),
-                ("wave_node_steps", C.c_uint64), ("wave_leaf_steps", C.c_uint64)]
+                ("wave_node_steps", C.c_uint64), ("wave_leaf_steps", C.c_uint64),
+                ("rays_closest_f32", C.c_uint64), ("ms_trace_closest_f32", C.c_double), ("launches_trace_closest_f32", C.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

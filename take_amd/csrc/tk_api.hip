@@ -136,7 +136,7 @@ struct EventPool {
     }
 };
 
-enum TimedKernel { TK_CLOSEST, TK_SHADOW, TK_SHADE, TK_OTHER, TK_NUM };
+enum TimedKernel { TK_CLOSEST, TK_SHADOW, TK_SHADE, TK_OTHER, TK_CLOSEST_TAIL /* mixed precision: closest hits of the f32 rounds */, TK_NUM };
 
 template <class R> struct SceneT {
     HostScene<R> host;  // kept: cheap relative to HBM copies, used for stats
@@ -716,7 +716,7 @@ struct RoundWs {
 // shadow rays.  (Everything is enqueued; nothing waits.)
 template <class RR>
 void launch_round(TakeScene *ts, SceneT<RR> &sc, const RoundWs &ws, PathState<RR> st, const RenderParams<RR> &rp, int k, int64_t n_bound,
-                  Timer &tm, bool counting, bool sort_materials, hipStream_t stream, int64_t dump, int64_t slots) {
+                  Timer &tm, bool counting, bool sort_materials, hipStream_t stream, int64_t dump, int64_t slots, bool tail = false) {
     int32_t *q = ws.q;
     int32_t *tag_count = q + Q_NUM_WORDS;
     const int cur = k & 1, next = cur ^ 1;
@@ -726,9 +726,9 @@ void launch_round(TakeScene *ts, SceneT<RR> &sc, const RoundWs &ws, PathState<RR
     // persistent trace grid, cut down when the queue (bounded by n_bound) cannot fill it: one block per 128 rays
     const dim3 tgrid((unsigned)std::max<int64_t>(1, std::min<int64_t>(sc.trace_grid, (n_bound + 127) / 128)));
     hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, stream, q, next);
-    tm.begin(TK_CLOSEST);
+    tm.begin(tail ? TK_CLOSEST_TAIL : TK_CLOSEST);
     launch_trace<RR>(sc.group, false, counting, tgrid, stream, sc.dev, io_ext, n_cur, 0, q + Q_HEAD_CLOSEST, ws.counters,
-                     (int)C_RAYS_CLOSEST, spill);
+                     tail ? (int)C_RAYS_CLOSEST_TAIL : (int)C_RAYS_CLOSEST, spill);
     tm.end();
     if (dump >= 0 && dump < slots) dump_slot(st, dump, "after trace_closest", k, stream);
     const int32_t *shade_in = ws.queue[cur];
@@ -903,7 +903,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
                                        q + ((k & 1) ? Q_N_EXT1 : Q_N_EXT0));
                     tm.end();
                 }
-                if (mixed && k >= exact_rounds) launch_round<float>(ts, ts->f, ws, st32, rp32, k, n_bound, tm, counting, sort_materials, stream, -1, slots);
+                if (mixed && k >= exact_rounds) launch_round<float>(ts, ts->f, ws, st32, rp32, k, n_bound, tm, counting, sort_materials, stream, -1, slots, true);
                 else launch_round<R>(ts, sc, ws, st, rp, k, n_bound, tm, counting, sort_materials, stream, dump, slots);
             } else {
                 launch_round<R>(ts, sc, ws, st, rp, k, n_bound, tm, counting, sort_materials, stream, dump, slots);
@@ -961,7 +961,8 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     HIP_TRY(hipMemcpy(c, sc.counters.p, sizeof c, hipMemcpyDeviceToHost));
     TakeCounters &tc = ts->counters;
     tc.samples = (uint64_t)npix * (uint64_t)o.spp;
-    tc.rays_closest = c[C_RAYS_CLOSEST];
+    tc.rays_closest = c[C_RAYS_CLOSEST] + c[C_RAYS_CLOSEST_TAIL];
+    tc.rays_closest_f32 = c[C_RAYS_CLOSEST_TAIL];
     tc.rays_shadow = c[C_RAYS_SHADOW];
     tc.node_visits = c[C_NODE_VISITS];
     tc.prim_tests = c[C_PRIM_TESTS];
@@ -974,14 +975,16 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
     tc.ms_total = ms;
-    double acc[TK_NUM] = {0, 0, 0, 0};
+    double acc[TK_NUM] = {0, 0, 0, 0, 0};
     for (auto &t : ts->timed) {
         float m = 0;
         if (hipEventElapsedTime(&m, t.second.first, t.second.second) == hipSuccess) acc[t.first] += m;
-        if (t.first == TK_CLOSEST) tc.launches_trace_closest++;
+        if (t.first == TK_CLOSEST || t.first == TK_CLOSEST_TAIL) tc.launches_trace_closest++;
+        if (t.first == TK_CLOSEST_TAIL) tc.launches_trace_closest_f32++;
         if (t.first == TK_SHADOW) tc.launches_trace_shadow++;
     }
-    tc.ms_trace_closest = acc[TK_CLOSEST];
+    tc.ms_trace_closest = acc[TK_CLOSEST] + acc[TK_CLOSEST_TAIL];
+    tc.ms_trace_closest_f32 = acc[TK_CLOSEST_TAIL];
     tc.ms_trace_shadow = acc[TK_SHADOW];
     tc.ms_shade = acc[TK_SHADE];
     tc.ms_other = acc[TK_OTHER];

@@ -271,7 +271,9 @@ enum QueueWord {
 // instrumentation counters (device, 64-bit)
 enum CounterWord {
     C_NODE_VISITS, C_PRIM_TESTS, C_RAYS_CLOSEST, C_RAYS_SHADOW, C_BOUNCES, C_LEAF_VISITS, C_WAVE_NODE_STEPS,
-    C_WAVE_LEAF_STEPS, C_WAIT_SLOTS, C_IDLE_SLOTS, C_NUM_WORDS = 12
+    C_WAVE_LEAF_STEPS, C_WAIT_SLOTS, C_IDLE_SLOTS,
+    C_RAYS_CLOSEST_TAIL,  // mixed-precision renders: the extend rays of the f32 rounds (also counted in C_RAYS_CLOSEST)
+    C_NUM_WORDS = 12
 };
 
 }  // namespace tk
