@@ -971,7 +971,8 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     tc.wave_node_steps = c[C_WAVE_NODE_STEPS];
     tc.wave_leaf_steps = c[C_WAVE_LEAF_STEPS];
     if (std::getenv("TAKE_HIP_VERBOSE"))
-        std::fprintf(stderr, "[take_hip] node-step ray slots: waiting-at-leaf %llu idle %llu running %llu\n", c[C_WAIT_SLOTS], c[C_IDLE_SLOTS], c[C_NODE_VISITS]);
+        std::fprintf(stderr, "[take_hip] node-step ray slots: waiting-at-leaf %llu idle %llu running %llu; shadow rays the slot's previous occluder stops again: %llu of %llu\n",
+                     c[C_WAIT_SLOTS], c[C_IDLE_SLOTS], c[C_NODE_VISITS], c[C_OCC_CACHE_HITS], c[C_RAYS_SHADOW]);
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
     tc.ms_total = ms;

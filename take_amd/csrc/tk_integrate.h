@@ -77,6 +77,7 @@ TK_HD void generate_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, co
     st.R_(S_LZ, slot) = R(0);
     st.I_(S_CTR, slot) = (int32_t)rng.ctr;
     st.I_(S_FLAGS, slot) = 0;
+    st.I_(S_OCC, slot) = -1;
 }
 
 constexpr uint32_t REQ_EXTEND = 1, REQ_SHADOW = 2;

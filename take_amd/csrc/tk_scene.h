@@ -245,9 +245,10 @@ enum StateR {
     S_CX, S_CY, S_CZ,          // throughput * C1: added to radiance if the shadow ray is unoccluded
     S_NUM_R = 29
 };
-enum StateI { S_HIT = 9, S_CTR = 10, S_FLAGS = 11, S_INST = 29, S_NUM_I = 4 };  // integer words of the same record
+enum StateI { S_HIT = 9, S_CTR = 10, S_FLAGS = 11, S_INST = 29, S_OCC = 30, S_NUM_I = 5 };  // integer words of the same record
 // S_HIT: index of the hit primitive (leaf order), -1 = the extend ray missed
 // S_INST: instance the hit primitive was reached through (two-level scenes only; -1 = none)
+// S_OCC: counting mode only (an instrument): the primitive that occluded this slot's previous shadow ray
 constexpr int PATH_REC = 32;
 constexpr int32_t FLAG_SPECULAR = 1;
 
@@ -273,6 +274,7 @@ enum CounterWord {
     C_NODE_VISITS, C_PRIM_TESTS, C_RAYS_CLOSEST, C_RAYS_SHADOW, C_BOUNCES, C_LEAF_VISITS, C_WAVE_NODE_STEPS,
     C_WAVE_LEAF_STEPS, C_WAIT_SLOTS, C_IDLE_SLOTS,
     C_RAYS_CLOSEST_TAIL,  // mixed-precision renders: the extend rays of the f32 rounds (also counted in C_RAYS_CLOSEST)
+    C_OCC_CACHE_HITS,     // counting mode: shadow rays that the previous occluder of their path slot occludes as well
     C_NUM_WORDS = 12
 };
 

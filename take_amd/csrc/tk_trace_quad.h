@@ -149,6 +149,11 @@ template <class R> struct PathIo {  // the render loop: rays in the path state, 
         st.R_(S_HV, slot) = v;
     }
     __device__ __forceinline__ void store_instance(int64_t slot, int32_t inst) const { st.I_(S_INST, slot) = inst; }
+    // counting mode (the instrumented instances): "would the previous occluder of this path slot have stopped this
+    // shadow ray too?" — the measurement behind DESIGN.md §7's answer to an occluder cache
+    static constexpr bool OCC_PROBE = true;
+    __device__ __forceinline__ int32_t last_occluder(int64_t slot) const { return st.I_(S_OCC, slot); }
+    __device__ __forceinline__ void set_last_occluder(int64_t slot, int32_t prim) const { st.I_(S_OCC, slot) = prim; }
     __device__ __forceinline__ void store_occlusion(int64_t slot, bool occluded) const {
         if (!occluded) {  // the NEE term of this iteration reaches the light (path_tracing.h:53-58)
             st.R_(S_LX, slot) = st.R_(S_LX, slot) + st.R_(S_CX, slot);
@@ -171,6 +176,9 @@ template <> struct HitAoS<double> {
 };
 template <class R> struct HookIo {  // the C-ABI trace hooks: AoS rays in, hit records out
     static constexpr bool UNIFORM_TMIN = false;
+    static constexpr bool OCC_PROBE = false;
+    __device__ __forceinline__ int32_t last_occluder(int64_t) const { return -1; }
+    __device__ __forceinline__ void set_last_occluder(int64_t, int32_t) const {}
     __device__ __forceinline__ R tmin() const { return R(0); }
     const PrimRec<R> *prims;
     const RayAoS<R> *rays;
@@ -320,6 +328,9 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
         if (ANY_HIT) {
             const bool occ = group_max_i<G>(my_prim) >= 0;
             if (gl == 0) io.store_occlusion(tag, occ);
+            if constexpr (COUNT && Io::OCC_PROBE && G == 1 && !INST) {
+                if (occ) io.set_last_occluder(tag, my_prim);
+            }
         } else {
             // the lane holding the closest candidate writes it.  At exactly equal distances (a ray through an edge
             // shared by two triangles) the candidate with the larger (u, v) wins, here and in the leaf phase — then, for
@@ -412,6 +423,21 @@ k_trace_group(DeviceScene<R> sc, Io io, const int32_t *__restrict__ n_ptr, int32
                         if (INST) inst = -1, my_inst = -1;
                         cur = sc.root_child;
                         if (sc.root_child == CHILD_EMPTY) finish();  // empty scene: a miss, the slot stays idle
+                        if constexpr (COUNT && ANY_HIT && Io::OCC_PROBE && G == 1 && !INST) {
+                            // instrument (counting instances only; the traversal goes on regardless): test the
+                            // primitive that occluded this slot's previous shadow ray against the new one
+                            const int32_t prev = io.last_occluder(tag);
+                            if (prev >= 0) {
+                                const PrimRec<R> &p = sc.prims[prev];
+                                R a9[9];
+                                for (int q9 = 0; q9 < 9; q9++) a9[q9] = p.a[q9];
+                                RayT<R> r2 = ray;
+                                if constexpr (Io::UNIFORM_TMIN) r2.tmin = io.tmin();
+                                R t2, u2 = R(0), v2 = R(0);
+                                const bool hit2 = ((p.meta & 0xff) == PRIM_TRIANGLE) ? tri_test(a9, r2, ray.tmax, t2, u2, v2) : sphere_test(a9, r2, ray.tmax, t2);
+                                if (hit2) atomicAdd(&counters[C_OCC_CACHE_HITS], 1ull);
+                            }
+                        }
                     }
                     pool_next += min(avail, (int32_t)(__builtin_popcountll(idle) >> GG::LOG2));
                 }
