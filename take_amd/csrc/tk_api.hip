@@ -799,7 +799,8 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     // paths in flight per batch: up to 512 Mi (69 GB of f32 path state + 9 GB of queues) — bigger batches keep the
     // persistent trace grid full for more of each bounce (measured on the 1M-triangle scene, spp per batch 8 / 16 / 32 /
     // 64 / 128 / 256 = 53.2 / 57.7 / 60.3 / 61.9 | 64.5 / 64.9 / 65.5 Msamples/s), and a 288 GB device has the room;
-    // capped at half of what is free now
+    // capped at four fifths of what is free now (round 3: it was half — a mixed-precision render, 418 B per path, then
+    // needed two batches for 256 spp at 1920x1080 and lost ~1 % to the second set of thin late rounds)
     int64_t target = (int64_t)512 << 20;
     {
         size_t free_b = 0, total_b = 0;
@@ -809,7 +810,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const int64_t have = (int64_t)sc.capacity * per_path;  // already allocated by an earlier render
             // (shards of a scene group that share a device size their batches concurrently: each takes its share)
-            target = std::min<int64_t>(target, std::max<int64_t>((int64_t)1 << 20, ((int64_t)free_b / std::max(1, ts->mem_share) + have) / 2 / per_path));
+            target = std::min<int64_t>(target, std::max<int64_t>((int64_t)1 << 20, ((int64_t)free_b / std::max(1, ts->mem_share) + have) / 5 * 4 / per_path));
         }
     }
     int spb = o.samples_per_batch > 0 ? o.samples_per_batch : (int)std::max<int64_t>(1, target / npix);
