@@ -448,7 +448,7 @@ std::string build_host_trees(const TakeSceneDesc &d, HostScene<R> &hs, std::vect
 
     qnodes.clear();
     {
-        // Both precisions traverse the 64-byte compressed nodes unless the 16-bit grid is too coarse for the
+        // Both precisions traverse the 64-byte compressed nodes unless the 15-bit grid is too coarse for the
         // geometry (child boxes growing by more than 10 % in area on average: a scene mixing scales by >1e4), or on request
         // (TAKE_HIP_NODES=wide / =q16: A/B runs).  In f64 scenes only the box tests use them (conservative, so
         // exactness is not at stake); hits are decided by the double-precision primitive tests.  Every tree of a

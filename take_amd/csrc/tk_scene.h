@@ -2,7 +2,7 @@
 //
 // Layout rules:
 //  * BVH: 4-wide nodes in breadth-first order (top levels = array prefix).  The render paths of both precisions read
-//    the 64-byte compressed form (QNode4: four 16-byte slots, planes on a 16-bit grid) — a lane loads its ray's
+//    the 64-byte compressed form (QNode4: four 16-byte slots, planes on a 15-bit grid) — a lane loads its ray's
 //    node with 4 x dwordx4, one 64-byte fabric request per node; the full-width form (Node4<R>) is the
 //    builder's output and the fall-back for scenes the grid is too coarse for.
 //  * Primitives are stored in leaf order as pre-transformed 64-byte records (v0, e1, e2 | centre, radius, then the
