@@ -816,8 +816,25 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     int spb = o.samples_per_batch > 0 ? o.samples_per_batch : (int)std::max<int64_t>(1, target / npix);
     spb = std::min(spb, o.spp);
     while ((int64_t)spb * npix >= ((int64_t)1 << 31) - (1 << 26)) spb--;
-    const int64_t slots = (int64_t)spb * npix;
-    int rc = ensure_workspace(sc, slots, npix);
+    // The free-memory figure above is a snapshot: another process on the device (or another host thread) may take the
+    // memory before the allocation lands.  A batch size the caller did not pin is then halved until it fits — the
+    // image does not depend on it (a sample's random stream is a function of seed, pixel and sample index only).
+    const bool mixed_records = sizeof(R) == 8 && ts->precision == TAKE_PRECISION_MIXED;
+    int64_t slots = 0;
+    int rc = TAKE_OK;
+    for (;;) {
+        slots = (int64_t)spb * npix;
+        rc = ensure_workspace(sc, slots, npix);
+        if (rc == TAKE_OK && mixed_records && (int64_t)ts->f.state_r.n < (int64_t)PATH_REC * slots &&
+            ts->f.state_r.alloc((size_t)PATH_REC * slots) != hipSuccess) {
+            ts->f.state_r.release();
+            release_workspace(sc);
+            rc = fail(TAKE_E_NOMEM, "out of device memory for the f32 path records of a mixed-precision render (" + std::to_string(slots) + " path slots)");
+        }
+        if (rc != TAKE_E_NOMEM || spb == 1 || o.samples_per_batch > 0) break;
+        (void)hipGetLastError();
+        spb = (spb + 1) / 2;
+    }
     if (rc) return rc;
 
     PathState<R> st{sc.state_r.p, sc.capacity};
@@ -859,10 +876,6 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
         if (mixed) {
             exact_rounds = o.exact_bounces > 0 ? o.exact_bounces : TAKE_DEFAULT_EXACT_BOUNCES;
             if (o.integrator != 0) return fail(TAKE_E_INVALID, "mixed precision renders the reference's path_tracing (integrator 0) only");
-            if ((int64_t)ts->f.state_r.n < (int64_t)PATH_REC * slots) {
-                if (ts->f.state_r.alloc((size_t)PATH_REC * slots) != hipSuccess)
-                    return fail(TAKE_E_NOMEM, "out of device memory for the f32 path records of a mixed-precision render");
-            }
             st32 = PathState<float>{ts->f.state_r.p, slots};
             rp32.width = rp.width, rp32.height = rp.height, rp32.n_local_rows = rp.n_local_rows, rp32.npix = rp.npix;
             rp32.strip_first = rp.strip_first, rp32.strip_stride = rp.strip_stride, rp32.spp = rp.spp, rp32.max_depth = rp.max_depth;

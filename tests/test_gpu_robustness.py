@@ -40,6 +40,22 @@ def test_failed_workspace_allocation_leaves_scene_usable(nth, monkeypatch):
         sc.close()
 
 
+@pytest.mark.parametrize("precision,nth", [(D.TAKE_PRECISION_F32, 1), (D.TAKE_PRECISION_MIXED, 1), (D.TAKE_PRECISION_MIXED, 7)])
+def test_unpinned_batch_shrinks_when_the_allocation_fails(precision, nth, monkeypatch):
+    """memory taken by someone else between the free-memory query and the allocation (two processes on one device):
+    a batch size the caller did not pin is halved until it fits, and the image is the same.  nth = 1: the path
+    state; 7 (mixed precision): the f32 records beside the f64 ones."""
+    sc = capi.Scene(golden_scene("cbox"), precision=precision)
+    try:
+        want = sc.render(spp=64, max_depth=5, seed=4, samples_per_batch=1)  # (framebuffer + a 1-spp workspace exist now)
+        monkeypatch.setenv("TAKE_HIP_FAIL_ALLOC", str(nth))
+        got = sc.render(spp=64, max_depth=5, seed=4)
+        monkeypatch.delenv("TAKE_HIP_FAIL_ALLOC")
+        assert np.array_equal(got, want)  # (without the retry the injected failure would have surfaced as TAKE_E_NOMEM)
+    finally:
+        sc.close()
+
+
 def test_batch_beyond_4gib_of_path_state_is_batch_invariant():
     sd = scenes.soup_scene(100_000, 1920, 1080, spp=17, materials="mixed")
     sc = capi.Scene(sd, precision=D.TAKE_PRECISION_F32)
