@@ -23,13 +23,14 @@
 #ifndef TAKE_HIP_H
 #define TAKE_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define TAKE_HIP_ABI_VERSION 4 /* 2: TakeSceneDesc.instances, TakeRenderOpts.integrator (was reserved); 3: take_hip_render_accumulate; 4: TAKE_PRECISION_MIXED, TakeRenderOpts.exact_bounces */
+#define TAKE_HIP_ABI_VERSION 5 /* 2: TakeSceneDesc.instances, TakeRenderOpts.integrator (was reserved); 3: take_hip_render_accumulate; 4: TAKE_PRECISION_MIXED, TakeRenderOpts.exact_bounces; 5: TakeMesh.flags (was reserved), take_hip_mesh_from_ply */
 
 /* error codes */
 #define TAKE_OK 0
@@ -111,8 +112,10 @@ typedef struct TakeMesh {
     const double *normals;   /* n_vertices * 3, or NULL (mesh.normals.empty()) */
     const double *uvs;       /* n_vertices * 2, or NULL (mesh.uvs.empty())     */
     int32_t material_id;
-    int32_t reserved;
+    int32_t flags;           /* 0, or TAKE_MESH_DEVICE_ARRAYS: the four arrays live in device memory (a mesh that
+                                take_hip_mesh_from_ply decoded there) */
 } TakeMesh;
+#define TAKE_MESH_DEVICE_ARRAYS 1
 
 /* reference `Sphere` (src/shape.h:20-23) */
 typedef struct TakeSphere {
@@ -380,6 +383,40 @@ int take_hip_set_instrumentation(TakeScene *scene, int32_t flags);
  * per row: the first random_real() draws of the mt19937 stream the reference used for that row. */
 int take_hip_debug_table(int32_t kind, int32_t precision, const double *in, int64_t n, int32_t in_cols,
                          const double *rnd, double *out, int32_t out_cols);
+
+/* ---- PLY -> device mesh arrays ------------------------------------------------------------
+ * Replaces src/parse/parse_ply.cpp:9-123 (`TriangleMesh parse_ply(filename, to_world)`) for binary_little_endian
+ * files: the host reads only the text header, the binary body goes to HBM as it lies in the file and kernels do what
+ * the reference's host loops do — widen x/y/z, nx/ny/nz, u/v to double, xform_point(to_world) on positions
+ * (src/transform.cpp:79-87), xform_normal(inverse(to_world)) on normals (src/transform.cpp:95-100), narrow the face
+ * list to int triples.  The arrays are bit-identical to the reference's `TriangleMesh` members.
+ * `to_world` / `inv_to_world`: the reference's Matrix4x4, row-major (m[4*i+j] = M(i,j)); NULL = identity.  The caller
+ * passes the inverse it already has (`inverse(to_world)`, src/matrix.h:81) — only meshes with normals read it.
+ * On success `*out` describes a mesh whose arrays are DEVICE memory owned by the library (flags =
+ * TAKE_MESH_DEVICE_ARRAYS): put it into a TakeSceneDesc like any other mesh, and give it back with
+ * take_hip_mesh_release once every scene_create that uses it has returned.
+ * Not decodable here (TAKE_E_INVALID, message starts with "unsupported"): ascii / big-endian files, list properties in
+ * the vertex element or ahead of the mesh data — the caller keeps its host parser for those.  Faces that are not
+ * triangles or index past the vertex array are TAKE_E_INVALID (the reference reads three indices per face
+ * unconditionally, parse_ply.cpp:85-120). */
+typedef struct TakePlyLayout {
+    int64_t n_vertices, n_faces;
+    int64_t vertex_offset, face_offset; /* bytes from the start of the file */
+    int32_t vertex_stride, face_stride; /* bytes per row (faces: with three indices) */
+    int32_t has_normals, has_uvs;
+    int32_t position_is_f64, index_bytes;
+    int32_t header_bytes, reserved;
+} TakePlyLayout;
+/* header only; needs no GPU */
+int take_hip_ply_layout(const void *file_bytes, size_t n_bytes, TakePlyLayout *out);
+int take_hip_mesh_from_ply(const void *file_bytes, size_t n_bytes, const double *to_world, const double *inv_to_world,
+                           int32_t material_id, TakeMesh *out);
+/* the same on a file (memory-mapped, so the body is read once, by the copy to the device) */
+int take_hip_mesh_from_ply_file(const char *path, const double *to_world, const double *inv_to_world,
+                                int32_t material_id, TakeMesh *out);
+/* copy a device-array mesh to host arrays the caller sized from n_vertices / n_faces (NULL = skip that array) */
+int take_hip_mesh_download(const TakeMesh *mesh, double *positions, int32_t *indices, double *normals, double *uvs);
+int take_hip_mesh_release(TakeMesh *mesh);
 
 /* BVH introspection (tests / DESIGN figures): node count, primitive count, depth */
 int take_hip_scene_stats(const TakeScene *scene, int64_t *n_nodes, int64_t *n_prims,

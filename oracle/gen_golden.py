@@ -438,6 +438,120 @@ def make_egress():
         run("imwrite", os.path.join(d, name + ".f64"), os.path.join(d, name + ".exr"))
 
 
+PLY_TYPES = {"char": "i1", "uchar": "u1", "short": "<i2", "ushort": "<u2", "int": "<i4", "uint": "<u4", "float": "<f4",
+             "double": "<f8", "int8": "i1", "uint8": "u1", "int16": "<i2", "uint16": "<u2", "int32": "<i4",
+             "uint32": "<u4", "float32": "<f4", "float64": "<f8"}
+
+
+def write_ply_general(path, vertex_props, vertex_cols, face_pre, count_type, index_type, faces, face_post=(),
+                      face_first=False, extra_element=False, comments=()):
+    """binary little-endian PLY with any scalar types / extra properties / element order (tests of the device decode).
+    vertex_props: [(type name, property name)], vertex_cols: {property name: column}; face_pre / face_post: scalar
+    properties around the `vertex_indices` list, [(type name, property name, column)]."""
+    nv = len(next(iter(vertex_cols.values())))
+    vdt = np.dtype([(n, PLY_TYPES[t]) for t, n in vertex_props])
+    vert = np.zeros(nv, vdt)
+    for _, n in vertex_props:
+        vert[n] = vertex_cols[n]
+    fdt = np.dtype([(n, PLY_TYPES[t]) for t, n, _ in face_pre] + [("cnt", PLY_TYPES[count_type]), ("idx", PLY_TYPES[index_type], 3)] +
+                   [(n, PLY_TYPES[t]) for t, n, _ in face_post])
+    face = np.zeros(len(faces), fdt)
+    face["cnt"] = 3
+    face["idx"] = faces
+    for _, n, col in list(face_pre) + list(face_post):
+        face[n] = col
+    vhdr = [f"element vertex {nv}"] + [f"property {t} {n}" for t, n in vertex_props]
+    fhdr = ([f"element face {len(faces)}"] + [f"property {t} {n}" for t, n, _ in face_pre] +
+            [f"property list {count_type} {index_type} vertex_indices"] + [f"property {t} {n}" for t, n, _ in face_post])
+    ehdr = ["element edge 3", "property int vertex1", "property int vertex2"] if extra_element else []
+    body = [face.tobytes(), vert.tobytes()] if face_first else [vert.tobytes(), face.tobytes()]
+    hdr = ["ply", "format binary_little_endian 1.0"] + [f"comment {c}" for c in comments]
+    hdr += (fhdr + vhdr) if face_first else (vhdr + fhdr)
+    hdr += ehdr + ["end_header"]
+    with open(path, "wb") as f:
+        f.write(("\n".join(hdr) + "\n").encode())
+        for b in body:
+            f.write(b)
+        if extra_element:
+            f.write(np.arange(6, dtype="<i4").tobytes())
+
+
+def ply_cases():
+    """name -> (writer kwargs, to_world 4x4): the encodings src/parse/parse_ply.cpp:9-123 accepts"""
+    rng = np.random.default_rng(2024)
+
+    def geometry(nv, nf):
+        pos = rng.uniform(-2.0, 2.0, (nv, 3))
+        nrm = rng.normal(size=(nv, 3))
+        uv = rng.uniform(0.0, 1.0, (nv, 2))
+        faces = rng.integers(0, nv, (nf, 3))
+        return pos, nrm, uv, faces
+
+    def rot(ax, a):
+        c, s_ = np.cos(a), np.sin(a)
+        m = np.eye(4)
+        i, j = [(1, 2), (0, 2), (0, 1)][ax]
+        m[i, i], m[i, j], m[j, i], m[j, j] = c, -s_, s_, c
+        return m
+
+    cases = {}
+    eye = np.eye(4)
+    affine = rot(0, 0.3) @ rot(1, -1.1) @ np.diag([1.5, 0.7, 2.0, 1.0])
+    affine[:3, 3] = (0.25, -3.0, 1.75)
+    persp = affine.copy()
+    persp[3] = (0.01, -0.02, 0.03, 1.25)  # w != 1: xform_point divides by it
+    # 1: the writer of scenes/*.ply: float positions, uchar count, int indices
+    pos, nrm, uv, faces = geometry(300, 500)
+    cases["f32_plain"] = (dict(vertex_props=[("float", "x"), ("float", "y"), ("float", "z")],
+                               vertex_cols={"x": pos[:, 0], "y": pos[:, 1], "z": pos[:, 2]}, face_pre=[], count_type="uchar",
+                               index_type="int", faces=faces), eye)
+    # 2: normals + uvs interleaved with properties nobody asked for, an affine to_world
+    pos, nrm, uv, faces = geometry(257, 401)
+    cols = {"x": pos[:, 0], "y": pos[:, 1], "z": pos[:, 2], "nx": nrm[:, 0], "ny": nrm[:, 1], "nz": nrm[:, 2], "u": uv[:, 0],
+            "v": uv[:, 1], "red": rng.integers(0, 255, 257), "quality": rng.uniform(size=257)}
+    cases["f32_normals_uvs_affine"] = (dict(
+        vertex_props=[("float", "x"), ("float", "y"), ("float", "z"), ("uchar", "red"), ("float", "nx"), ("float", "ny"),
+                      ("float", "nz"), ("double", "quality"), ("float", "u"), ("float", "v")],
+        vertex_cols=cols, face_pre=[], count_type="uchar", index_type="uint", faces=faces, comments=("made by gen_golden",)), affine)
+    # 3: everything double, homogeneous to_world, a zero normal (normalize() returns the zero vector)
+    pos, nrm, uv, faces = geometry(129, 200)
+    nrm[7] = 0.0
+    cols = {"x": pos[:, 0], "y": pos[:, 1], "z": pos[:, 2], "nx": nrm[:, 0], "ny": nrm[:, 1], "nz": nrm[:, 2], "u": uv[:, 0], "v": uv[:, 1]}
+    cases["f64_all_projective"] = (dict(
+        vertex_props=[("double", n) for n in ("x", "y", "z", "nx", "ny", "nz", "u", "v")], vertex_cols=cols, face_pre=[],
+        count_type="uint8", index_type="int32", faces=faces), persp)
+    # 4: 16-bit indices, scalar face properties on both sides of the list, faces ahead of the vertices, a trailing element
+    pos, nrm, uv, faces = geometry(1000, 777)
+    cases["u16_faces_first"] = (dict(
+        vertex_props=[("float32", "x"), ("float32", "y"), ("float32", "z"), ("float32", "u"), ("float32", "v")],
+        vertex_cols={"x": pos[:, 0], "y": pos[:, 1], "z": pos[:, 2], "u": uv[:, 0], "v": uv[:, 1]},
+        face_pre=[("uchar", "flags", rng.integers(0, 255, 777))], count_type="uchar", index_type="ushort", faces=faces,
+        face_post=[("float", "area", rng.uniform(size=777))], face_first=True, extra_element=True), affine)
+    # 5: 8-bit indices, a 16-bit count
+    pos, nrm, uv, faces = geometry(100, 64)
+    cases["i8_indices"] = (dict(vertex_props=[("float", "x"), ("float", "y"), ("float", "z"), ("float", "nx"), ("float", "ny"), ("float", "nz")],
+                                vertex_cols={"x": pos[:, 0], "y": pos[:, 1], "z": pos[:, 2], "nx": nrm[:, 0], "ny": nrm[:, 1], "nz": nrm[:, 2]},
+                                face_pre=[], count_type="ushort", index_type="char", faces=faces), rot(2, 0.5))
+    pos, nrm, uv, faces = geometry(200, 90)
+    cases["u8_i16"] = (dict(vertex_props=[("double", "x"), ("double", "y"), ("double", "z")],
+                            vertex_cols={"x": pos[:, 0], "y": pos[:, 1], "z": pos[:, 2]}, face_pre=[], count_type="int",
+                            index_type="short", faces=faces), eye)
+    return cases
+
+
+def make_ply():
+    """tests/golden/ply/: PLY files in every encoding the reference's parse_ply reads, its to_world matrices, and the
+    TriangleMesh arrays the reference's own parser (ref_harness ply) made of them"""
+    d = os.path.join(GOLD, "ply")
+    os.makedirs(d, exist_ok=True)
+    for name, (kw, xf) in ply_cases().items():
+        write_ply_general(os.path.join(d, name + ".ply"), **kw)
+        np.asarray(xf, "<f8").reshape(-1).tofile(os.path.join(d, name + "_xform.f64"))
+        run("ply", os.path.join(d, name + ".ply"), os.path.join(d, name + "_xform.f64"), os.path.join(d, name + "_mesh.f64"))
+        out = np.fromfile(os.path.join(d, name + "_mesh.f64"), "<f8")
+        print(f"ply/{name}: {int(out[0])} vertices, {int(out[1])} faces, normals {int(out[2])}, uvs {int(out[3])}")
+
+
 def main():
     if not os.path.exists(HARNESS):
         raise SystemExit("oracle/_ref/ref_harness missing: run `make -C oracle ref` (needs /root/reference)")
@@ -449,6 +563,9 @@ def main():
         return
     if sys.argv[1:] == ["disney"]:
         make_disney()
+        return
+    if sys.argv[1:] == ["ply"]:
+        make_ply()
         return
     man = {}
     names = make_scene_files()

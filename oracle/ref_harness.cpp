@@ -18,6 +18,7 @@
 //
 // Tables are raw little-endian float64, row-major; the column layouts are defined by
 // oracle/gen_golden.py, which generates the inputs and documents the outputs.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -28,6 +29,7 @@
 
 #include "image.h"
 #include "parallel.h"
+#include "parse/parse_ply.h"
 #include "parse/parse_scene.h"
 #include "render.h"
 #include "scene.h"
@@ -138,6 +140,39 @@ int main(int argc, char **argv) {
         take_hip::FlatScene flat;
         take_hip::flatten_scene(scene, flat);
         take_hip::write_tkscene(argv[3], flat.desc, scene.options.spp, scene.options.max_depth);
+        return 0;
+    }
+    if (cmd == "ply") {
+        // ply <mesh.ply> <in.f64: to_world, 16 doubles row-major> <out.f64>   the reference's own parse_ply
+        // (src/parse/parse_ply.cpp:9-123).  out: nv nf has_normals has_uvs, the reference's inverse(to_world) (16, what
+        // parse_ply pushes the normals through), then positions (3 nv), indices (3 nf, as doubles), normals (3 nv if
+        // any), uvs (2 nv if any)
+        auto in = read_f64(argv[3]);
+        Matrix4x4 m;
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) m(i, j) = in[4 * i + j];
+        TriangleMesh mesh = parse_ply(argv[2], m);
+        std::vector<double> o;
+        o.push_back((double)mesh.positions.size());
+        o.push_back((double)mesh.indices.size());
+        o.push_back(mesh.normals.empty() ? 0.0 : 1.0);
+        o.push_back(mesh.uvs.empty() ? 0.0 : 1.0);
+        const Matrix4x4 inv = inverse(m);
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) o.push_back(inv(i, j));
+        for (auto &v : mesh.positions) push3(o, v);
+        for (auto &f : mesh.indices) o.push_back(f[0]), o.push_back(f[1]), o.push_back(f[2]);
+        for (auto &v : mesh.normals) push3(o, v);
+        for (auto &v : mesh.uvs) o.push_back(v.x), o.push_back(v.y);
+        write_f64(argv[4], o);
+        return 0;
+    }
+    if (cmd == "ply_time") {
+        // ply_time <mesh.ply>   seconds the reference's parse_ply takes on this host (tools/diag_ply.py)
+        const auto t0 = std::chrono::steady_clock::now();
+        TriangleMesh mesh = parse_ply(argv[2], Matrix4x4::identity());
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("%.6f %zu %zu\n", s, mesh.positions.size(), mesh.indices.size());
         return 0;
     }
     if (cmd == "random_real") {

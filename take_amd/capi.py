@@ -23,6 +23,7 @@ EXPORTS = [
     "take_hip_set_instrumentation", "take_hip_scene_stats", "take_hip_debug_table",
     "take_hip_group_create", "take_hip_group_destroy", "take_hip_group_render", "take_hip_group_render_device",
     "take_hip_group_size", "take_hip_group_get_counters", "take_hip_pack_exr_scanlines", "take_hip_render_exr_scanlines",
+    "take_hip_ply_layout", "take_hip_mesh_from_ply", "take_hip_mesh_from_ply_file", "take_hip_mesh_download", "take_hip_mesh_release",
 ]
 
 
@@ -77,6 +78,11 @@ def lib():
         L.take_hip_group_render_device.argtypes = [C.c_void_p, C.POINTER(D.TakeRenderOpts), C.c_void_p]
         L.take_hip_group_size.argtypes = [C.c_void_p]
         L.take_hip_group_get_counters.argtypes = [C.c_void_p, C.c_int32, C.POINTER(D.TakeCounters)]
+        L.take_hip_ply_layout.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(D.TakePlyLayout)]
+        L.take_hip_mesh_from_ply.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(D.TakeMesh)]
+        L.take_hip_mesh_from_ply_file.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(D.TakeMesh)]
+        L.take_hip_mesh_download.argtypes = [C.POINTER(D.TakeMesh), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.take_hip_mesh_release.argtypes = [C.POINTER(D.TakeMesh)]
         _LIB = L
     return _LIB
 
@@ -89,6 +95,61 @@ def _check(rc):
 
 def device_count():
     return _check(lib().take_hip_device_count())
+
+
+def ply_layout(data):
+    """what the header of a binary PLY file says about its vertex / face elements (host only, no GPU)"""
+    buf = bytes(data)
+    out = D.TakePlyLayout()
+    _check(lib().take_hip_ply_layout(buf, len(buf), C.byref(out)))
+    return {k: getattr(out, k) for k, _ in D.TakePlyLayout._fields_ if k != "reserved"}
+
+
+class DeviceMesh:
+    """A triangle mesh decoded from a binary PLY file ON the device (take_hip_mesh_from_ply: replaces the reference's
+    parse_ply, src/parse/parse_ply.cpp:9-123).  The arrays are device memory owned by the library; put the object into
+    SceneData.meshes like a scene.Mesh.  `source`: a path or the file's bytes.  to_world: 4x4 (the reference's Matrix4x4);
+    inv_to_world: the caller's inverse of it (the reference passes its own `inverse(to_world)`), default numpy's."""
+
+    def __init__(self, source, material_id=0, to_world=None, inv_to_world=None):
+        self.c = D.TakeMesh()
+        xw = xi = None
+        if to_world is not None:
+            xw = np.ascontiguousarray(to_world, np.float64).reshape(4, 4)
+            xi = np.ascontiguousarray(np.linalg.inv(xw) if inv_to_world is None else inv_to_world, np.float64).reshape(4, 4)
+        a = None if xw is None else xw.ctypes.data
+        b = None if xi is None else xi.ctypes.data
+        if isinstance(source, (bytes, bytearray, memoryview)):
+            buf = bytes(source)
+            _check(lib().take_hip_mesh_from_ply(buf, len(buf), a, b, int(material_id), C.byref(self.c)))
+        else:
+            _check(lib().take_hip_mesh_from_ply_file(os.fsencode(source), a, b, int(material_id), C.byref(self.c)))
+        self.material_id = int(material_id)
+
+    n_vertices = property(lambda self: int(self.c.n_vertices))
+    n_faces = property(lambda self: int(self.c.n_faces))
+
+    def download(self):
+        """-> scene.Mesh with host copies of the arrays (tests; the render path never needs it)"""
+        from .scene import Mesh
+
+        nv, nf = self.n_vertices, self.n_faces
+        pos, idx = np.zeros((nv, 3), np.float64), np.zeros((nf, 3), np.int32)
+        nrm = np.zeros((nv, 3), np.float64) if self.c.normals else None
+        uv = np.zeros((nv, 2), np.float64) if self.c.uvs else None
+        _check(lib().take_hip_mesh_download(C.byref(self.c), pos.ctypes.data, idx.ctypes.data,
+                                            None if nrm is None else nrm.ctypes.data, None if uv is None else uv.ctypes.data))
+        return Mesh(pos, idx, self.material_id, nrm, uv)
+
+    def close(self):
+        if self.c.flags:
+            lib().take_hip_mesh_release(C.byref(self.c))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 DEBUG_TABLES = {"material": (0, 27, 14), "light": (1, 30, 9), "texture": (2, 6, 3), "to_world": (3, 6, 3),

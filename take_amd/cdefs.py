@@ -33,7 +33,16 @@ class TakeImage3(C.Structure):
 class TakeMesh(C.Structure):
     _fields_ = [("n_vertices", C.c_int64), ("n_faces", C.c_int64), ("positions", C.POINTER(C.c_double)),
                 ("indices", C.POINTER(C.c_int32)), ("normals", C.POINTER(C.c_double)), ("uvs", C.POINTER(C.c_double)),
-                ("material_id", C.c_int32), ("reserved", C.c_int32)]
+                ("material_id", C.c_int32), ("flags", C.c_int32)]
+
+
+TAKE_MESH_DEVICE_ARRAYS = 1
+
+
+class TakePlyLayout(C.Structure):
+    _fields_ = [("n_vertices", C.c_int64), ("n_faces", C.c_int64), ("vertex_offset", C.c_int64), ("face_offset", C.c_int64),
+                ("vertex_stride", C.c_int32), ("face_stride", C.c_int32), ("has_normals", C.c_int32), ("has_uvs", C.c_int32),
+                ("position_is_f64", C.c_int32), ("index_bytes", C.c_int32), ("header_bytes", C.c_int32), ("reserved", C.c_int32)]
 
 
 class TakeSphere(C.Structure):

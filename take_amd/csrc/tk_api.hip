@@ -16,10 +16,16 @@
 #include <thread>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "take_hip.h"
 #include "tk_host_scene.h"
 #include "tk_build_gpu.h"
 #include "tk_kernels.h"
+#include "tk_ply.h"
 
 using namespace tk;
 
@@ -334,10 +340,72 @@ int build_bvh_device(SceneT<float> &sc, int max_leaf, bool compressed_ok, bool c
     HIP_TRY(hipGetLastError());
     return TAKE_OK;
 }
+// Device-array meshes (TAKE_MESH_DEVICE_ARRAYS, take_hip_mesh_from_ply) in a scene description: the host side of the
+// build — index validation, the face / normal / uv tables, the SAH builder — reads host copies, staged here.
+struct StagedMeshes {
+    bool any = false;
+    std::vector<TakeMesh> meshes;            // what the build sees (d.meshes points here)
+    std::vector<const double *> d_positions;  // per mesh: its device positions while they have not been staged
+    std::vector<std::vector<double>> reals;
+    std::vector<std::vector<int32_t>> ints;
+    hipError_t real(const double *&p, size_t n) {
+        if (!p || n == 0) return hipSuccess;
+        reals.emplace_back(n);
+        const hipError_t e = hipMemcpy(reals.back().data(), p, n * sizeof(double), hipMemcpyDeviceToHost);
+        p = reals.back().data();
+        return e;
+    }
+    // all_positions: the host builder will run (it reads every vertex).  Otherwise only the meshes an area light
+    // sits on bring their positions to the host (the light records are made there); the device build copies the
+    // others device-to-device.
+    int stage(TakeSceneDesc &d, bool all_positions) {
+        for (int i = 0; i < d.n_meshes; i++) any = any || (d.meshes && (d.meshes[i].flags & TAKE_MESH_DEVICE_ARRAYS));
+        if (!any) return TAKE_OK;
+        meshes.assign(d.meshes, d.meshes + d.n_meshes);
+        d_positions.assign((size_t)d.n_meshes, nullptr);
+        std::vector<char> emissive((size_t)d.n_meshes, 0);
+        for (int i = 0; i < d.n_lights; i++) {
+            const TakeLight &l = d.lights[i];
+            if (l.kind != 1 || l.shape_id < 0 || l.shape_id >= d.n_shapes || d.shape_kind[l.shape_id] != 1) continue;
+            const int32_t mi = d.shape_ref[l.shape_id];
+            if (mi >= 0 && mi < d.n_meshes) emissive[mi] = 1;
+        }
+        for (int i = 0; i < d.n_meshes; i++) {
+            TakeMesh &m = meshes[i];
+            if (!(m.flags & TAKE_MESH_DEVICE_ARRAYS)) continue;
+            if (m.n_vertices < 0 || m.n_faces < 0) return fail(TAKE_E_INVALID, "negative mesh size");
+            if (all_positions || emissive[i]) HIP_TRY(real(m.positions, 3 * (size_t)m.n_vertices));
+            else d_positions[i] = m.positions;
+            HIP_TRY(real(m.normals, 3 * (size_t)m.n_vertices));
+            HIP_TRY(real(m.uvs, 2 * (size_t)m.n_vertices));
+            if (m.indices && m.n_faces > 0) {
+                ints.emplace_back(3 * (size_t)m.n_faces);
+                HIP_TRY(hipMemcpy(ints.back().data(), m.indices, ints.back().size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+                m.indices = ints.back().data();
+            }
+            m.flags &= ~TAKE_MESH_DEVICE_ARRAYS;
+        }
+        d.meshes = meshes.data();
+        return TAKE_OK;
+    }
+    // the device build gave up (tree too deep): the host builder needs every vertex after all
+    int ensure_positions() {
+        for (size_t i = 0; i < meshes.size(); i++) {
+            if (!d_positions[i]) continue;
+            HIP_TRY(real(meshes[i].positions, 3 * (size_t)meshes[i].n_vertices));
+            d_positions[i] = nullptr;
+        }
+        return TAKE_OK;
+    }
+};
+thread_local StagedMeshes *t_staged = nullptr;  // set by scene_create while upload_scene runs on a staged description
+
 // Primitive records on the device from the caller's arrays (tk_build_gpu.h::k_make_prims): the mesh positions go up as
 // they are (double, one copy per mesh, no host staging), the face indices are the validated concatenation the shading
 // side keeps anyway (sc.face_idx, uploaded here), the four shape arrays go up as they are.
-int make_prims_on_device(SceneT<float> &sc, const TakeSceneDesc &d) {
+// device_positions: per mesh, positions that are in device memory already (a mesh take_hip_mesh_from_ply decoded; the
+// description then holds host copies of what the host side validates and tabulates, not of these), or null
+int make_prims_on_device(SceneT<float> &sc, const TakeSceneDesc &d, const double *const *device_positions) {
     using namespace lbvh;
     const int n = (int)d.n_shapes;
     HostScene<float> &h = sc.host;
@@ -363,9 +431,15 @@ int make_prims_on_device(SceneT<float> &sc, const TakeSceneDesc &d) {
     } cleanup{[&] { d_pos.release(), d_kind.release(), d_ref.release(), d_face.release(), d_al.release(), d_ms.release(), d_ss.release(); }};
     HIP_TRY(d_pos.alloc(3 * (size_t)std::max<int64_t>(nv, 1)));
     PinnedUploads pin;
-    for (int i = 0; i < d.n_meshes; i++)
-        if (d.meshes[i].n_vertices > 0)
-            HIP_TRY(pin.copy(d_pos.p + 3 * ms[i].pos_off, d.meshes[i].positions, sizeof(double) * 3 * (size_t)d.meshes[i].n_vertices));
+    for (int i = 0; i < d.n_meshes; i++) {
+        if (d.meshes[i].n_vertices <= 0) continue;
+        const size_t bytes = sizeof(double) * 3 * (size_t)d.meshes[i].n_vertices;
+        // a mesh decoded on the device (take_hip_mesh_from_ply): its positions never were on the host
+        if (device_positions && device_positions[i])
+            HIP_TRY(hipMemcpyAsync(d_pos.p + 3 * ms[i].pos_off, device_positions[i], bytes, hipMemcpyDeviceToDevice, pin.stream));
+        else
+            HIP_TRY(pin.copy(d_pos.p + 3 * ms[i].pos_off, d.meshes[i].positions, bytes));
+    }
     HIP_TRY(sc.face_idx.upload(h.face_idx));
     auto up = [&](DevBuf<int32_t> &b, const int32_t *src) -> hipError_t {
         hipError_t e = b.alloc((size_t)n);
@@ -386,7 +460,7 @@ int make_prims_on_device(SceneT<float> &sc, const TakeSceneDesc &d) {
         std::fprintf(stderr, "[take_hip] scene_create: uploads pinned in place %.1f MB, pageable %.1f MB\n", pin.pinned_bytes / 1e6, pin.plain_bytes / 1e6);
     return TAKE_OK;
 }
-template <class R> int make_prims_on_device(SceneT<R> &, const TakeSceneDesc &) { return 1; }
+template <class R> int make_prims_on_device(SceneT<R> &, const TakeSceneDesc &, const double *const *) { return 1; }
 
 // phase timer of scene_create (TAKE_HIP_VERBOSE=1 prints the phases to stderr)
 struct PhaseClock {
@@ -427,7 +501,7 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
     if (on_device) {
         int rc = TAKE_OK;
         if constexpr (sizeof(R) == 4) {
-            rc = make_prims_on_device(sc, desc);
+            rc = make_prims_on_device(sc, desc, t_staged && t_staged->any ? t_staged->d_positions.data() : nullptr);
             clock.lap("mesh arrays -> HBM, records");
             if (!rc) rc = build_bvh_device(sc, max_leaf, sc.group <= 2 && fmt != "wide", fmt == "q16");
         } else {
@@ -435,6 +509,10 @@ template <class R> int upload_scene(TakeScene *ts, const TakeSceneDesc &desc, co
         }
         if (rc == 1) {  // not buildable on the device (tree too deep): do it on the host after all
             on_device = false;
+            if (t_staged && t_staged->any) {
+                const int rs = t_staged->ensure_positions();
+                if (rs) return rs;
+            }
             err = prepare_scene<R>(desc, max_leaf, threads, sc.host, PREP_ALL, opts.burley_lobes != 0);
             if (!err.empty()) return fail(TAKE_E_INVALID, err);
         } else if (rc != TAKE_OK) {
@@ -1102,11 +1180,147 @@ int check_device() {
 
 }  // namespace
 
+// ---- PLY -> device mesh arrays (tk_ply.h) --------------------------------------------------------------------------
+namespace {
+void fill_layout(const ply::Layout &L, TakePlyLayout *o) {
+    std::memset(o, 0, sizeof(*o));
+    o->n_vertices = L.n_vertices, o->n_faces = L.n_faces;
+    o->vertex_offset = L.vertex_off, o->face_offset = L.face_off;
+    o->vertex_stride = L.vertex_stride, o->face_stride = L.face_stride;
+    o->has_normals = L.nrm_type != ply::T_NONE, o->has_uvs = L.uv_type != ply::T_NONE;
+    o->position_is_f64 = L.pos_type == ply::T_F64, o->index_bytes = ply::type_size(L.index_type);
+    o->header_bytes = L.header_bytes;
+}
+
+void free_mesh_arrays(TakeMesh *m) {
+    if (m->positions) (void)hipFree(const_cast<double *>(m->positions));
+    if (m->indices) (void)hipFree(const_cast<int32_t *>(m->indices));
+    if (m->normals) (void)hipFree(const_cast<double *>(m->normals));
+    if (m->uvs) (void)hipFree(const_cast<double *>(m->uvs));
+    std::memset(m, 0, sizeof(*m));
+}
+}  // namespace
+
 extern "C" {
 
 const char *take_hip_last_error(void) { return g_error.c_str(); }
 int take_hip_abi_version(void) { return TAKE_HIP_ABI_VERSION; }
 int take_hip_device_count(void) { return check_device(); }
+
+int take_hip_ply_layout(const void *file_bytes, size_t n_bytes, TakePlyLayout *out) {
+    if (!file_bytes || !out) return fail(TAKE_E_INVALID, "null argument");
+    ply::Layout L;
+    const std::string err = ply::parse_header((const uint8_t *)file_bytes, n_bytes, L);
+    if (!err.empty()) return fail(TAKE_E_INVALID, err);
+    fill_layout(L, out);
+    return TAKE_OK;
+}
+
+int take_hip_mesh_from_ply(const void *file_bytes, size_t n_bytes, const double *to_world, const double *inv_to_world,
+                           int32_t material_id, TakeMesh *out) {
+    if (!file_bytes || !out) return fail(TAKE_E_INVALID, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    ply::Layout L;
+    const std::string err = ply::parse_header((const uint8_t *)file_bytes, n_bytes, L);
+    if (!err.empty()) return fail(TAKE_E_INVALID, err);
+    const int nd = check_device();
+    if (nd < 0) return nd;
+    ply::Mat4 X, Xi;
+    static const double I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::memcpy(X.m, to_world ? to_world : I, sizeof(I));
+    std::memcpy(Xi.m, inv_to_world ? inv_to_world : I, sizeof(I));
+    if (to_world && !inv_to_world && L.nrm_type != ply::T_NONE)
+        return fail(TAKE_E_INVALID, "the file has normals: pass inverse(to_world) along with to_world");
+    // the body as it lies in the file: one copy, from the first to the last byte the two elements span
+    const int64_t lo = std::min(L.vertex_off, L.face_off);
+    DevBuf<uint8_t> body;
+    DevBuf<int32_t> status;
+    TakeMesh m{};
+    m.n_vertices = L.n_vertices, m.n_faces = L.n_faces, m.material_id = material_id, m.flags = TAKE_MESH_DEVICE_ARRAYS;
+    auto bail = [&](int rc) {
+        body.release(), status.release();
+        free_mesh_arrays(&m);
+        return rc;
+    };
+    auto dmalloc = [&](auto *&p, size_t count) -> bool {
+        void *q = nullptr;
+        if (count == 0) return true;
+        if (inject_alloc_failure() || hipMalloc(&q, count * sizeof(*p)) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        p = (std::remove_reference_t<decltype(p)>)q;
+        return true;
+    };
+    double *pos = nullptr, *nrm = nullptr, *uv = nullptr;
+    int32_t *idx = nullptr;
+    const bool ok = body.alloc((size_t)std::max<int64_t>(L.end_off - lo, 1)) == hipSuccess && status.alloc(1) == hipSuccess &&
+                    dmalloc(pos, 3 * (size_t)L.n_vertices) && dmalloc(idx, 3 * (size_t)L.n_faces) &&
+                    (L.nrm_type == ply::T_NONE || dmalloc(nrm, 3 * (size_t)L.n_vertices)) &&
+                    (L.uv_type == ply::T_NONE || dmalloc(uv, 2 * (size_t)L.n_vertices));
+    m.positions = pos, m.indices = idx, m.normals = nrm, m.uvs = uv;
+    if (!ok) return bail(fail(TAKE_E_NOMEM, "out of device memory for a " + std::to_string(L.n_faces) + "-face PLY mesh"));
+    {
+        PinnedUploads pin;
+        hipError_t e = pin.copy(body.p, (const uint8_t *)file_bytes + lo, (size_t)(L.end_off - lo));
+        if (e == hipSuccess) e = hipMemsetAsync(status.p, 0, sizeof(int32_t), pin.stream);
+        ply::Layout D = L;  // offsets relative to the copied span
+        D.vertex_off -= lo, D.face_off -= lo;
+        constexpr int BLK = 256;
+        if (e == hipSuccess && L.n_vertices > 0)
+            hipLaunchKernelGGL(ply::k_ply_vertices, dim3((unsigned)((L.n_vertices + BLK - 1) / BLK)), dim3(BLK), 0, pin.stream, body.p, D, X, Xi, pos, nrm, uv);
+        if (e == hipSuccess && L.n_faces > 0)
+            hipLaunchKernelGGL(ply::k_ply_faces, dim3((unsigned)((L.n_faces + BLK - 1) / BLK)), dim3(BLK), 0, pin.stream, body.p, D, idx, status.p);
+        if (e == hipSuccess) e = hipGetLastError();
+        int32_t st = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&st, status.p, sizeof(st), hipMemcpyDeviceToHost, pin.stream);
+        if (e == hipSuccess) e = pin.finish();
+        if (e != hipSuccess) return bail(fail(TAKE_E_DEVICE, std::string("PLY decode: ") + hipGetErrorString(e)));
+        if (st & 1) return bail(fail(TAKE_E_INVALID, "a face of the PLY file is not a triangle (the reference reads three indices per face)"));
+        if (st & 2) return bail(fail(TAKE_E_INVALID, "a face of the PLY file indexes past its vertex array"));
+    }
+    body.release(), status.release();
+    *out = m;
+    return TAKE_OK;
+}
+
+int take_hip_mesh_from_ply_file(const char *path, const double *to_world, const double *inv_to_world, int32_t material_id, TakeMesh *out) {
+    if (!path || !out) return fail(TAKE_E_INVALID, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(TAKE_E_INVALID, std::string("cannot open ") + path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || sb.st_size <= 0) {
+        close(fd);
+        return fail(TAKE_E_INVALID, std::string("cannot read ") + path);
+    }
+    void *p = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return fail(TAKE_E_INVALID, std::string("cannot map ") + path);
+    (void)madvise(p, (size_t)sb.st_size, MADV_SEQUENTIAL);
+    const int rc = take_hip_mesh_from_ply(p, (size_t)sb.st_size, to_world, inv_to_world, material_id, out);
+    munmap(p, (size_t)sb.st_size);
+    return rc;
+}
+
+int take_hip_mesh_download(const TakeMesh *m, double *positions, int32_t *indices, double *normals, double *uvs) {
+    if (!m) return fail(TAKE_E_INVALID, "null mesh");
+    if (!(m->flags & TAKE_MESH_DEVICE_ARRAYS)) return fail(TAKE_E_INVALID, "not a device-array mesh");
+    auto down = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+        return (dst && src && bytes) ? hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) : hipSuccess;
+    };
+    HIP_TRY(down(positions, m->positions, sizeof(double) * 3 * (size_t)m->n_vertices));
+    HIP_TRY(down(indices, m->indices, sizeof(int32_t) * 3 * (size_t)m->n_faces));
+    HIP_TRY(down(normals, m->normals, sizeof(double) * 3 * (size_t)m->n_vertices));
+    HIP_TRY(down(uvs, m->uvs, sizeof(double) * 2 * (size_t)m->n_vertices));
+    return TAKE_OK;
+}
+
+int take_hip_mesh_release(TakeMesh *m) {
+    if (!m) return TAKE_OK;
+    if (m->flags & TAKE_MESH_DEVICE_ARRAYS) free_mesh_arrays(m);
+    return TAKE_OK;
+}
 
 int take_hip_scene_create(const TakeSceneDesc *desc, const TakeBuildOpts *opts, TakeScene **out) {
     if (!desc || !out) return fail(TAKE_E_INVALID, "null argument");
@@ -1131,8 +1345,20 @@ int take_hip_scene_create(const TakeSceneDesc *desc, const TakeBuildOpts *opts, 
     ts->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int rc;
     try {
-        rc = o.precision != TAKE_PRECISION_F32 ? upload_scene<double>(ts, *desc, o) : upload_scene<float>(ts, *desc, o);
-        if (!rc && o.precision == TAKE_PRECISION_MIXED) rc = upload_scene<float>(ts, *desc, o);  // the same scene in f32 beside it
+        // device-array meshes (take_hip_mesh_from_ply): the host side of the build — index validation, the face / normal /
+        // uv tables, the SAH builder below TAKE_AUTO_DEVICE_BUILD_SHAPES shapes — reads host copies; the device build
+        // takes the positions where they are
+        StagedMeshes staged;
+        TakeSceneDesc local = *desc;
+        const bool device_build = o.precision == TAKE_PRECISION_F32 && desc->n_shapes >= 8 && desc->n_instances == 0 &&
+                                  (o.builder == TAKE_BUILDER_DEVICE_LBVH || (o.builder == TAKE_BUILDER_AUTO && desc->n_shapes >= TAKE_AUTO_DEVICE_BUILD_SHAPES));
+        rc = staged.stage(local, !device_build);
+        struct Reset {
+            ~Reset() { t_staged = nullptr; }
+        } reset;
+        t_staged = &staged;
+        if (!rc) rc = o.precision != TAKE_PRECISION_F32 ? upload_scene<double>(ts, local, o) : upload_scene<float>(ts, local, o);
+        if (!rc && o.precision == TAKE_PRECISION_MIXED) rc = upload_scene<float>(ts, local, o);  // the same scene in f32 beside it
     } catch (const std::bad_alloc &) {
         rc = fail(TAKE_E_NOMEM, "out of host memory while preparing the scene");
     } catch (const std::exception &e) {

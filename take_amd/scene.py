@@ -200,6 +200,11 @@ class SceneData:
         d.background = D.c_double3(*self.background)
         meshes = (D.TakeMesh * max(len(self.meshes), 1))()
         for i, m in enumerate(self.meshes):
+            if hasattr(m, "c"):  # capi.DeviceMesh: arrays already in device memory (decoded there from a PLY file)
+                meshes[i] = m.c
+                meshes[i].material_id = m.material_id
+                keep.append(m)
+                continue
             pos = np.ascontiguousarray(m.positions, np.float64)
             idx = np.ascontiguousarray(m.indices, np.int32)
             meshes[i].n_vertices = pos.shape[0]

@@ -37,7 +37,7 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.take_hip_abi_version() == 4
+    assert lib.take_hip_abi_version() == 5
 
 
 def test_struct_layout_matches_header():
@@ -46,7 +46,7 @@ def test_struct_layout_matches_header():
         "TakeMesh": D.TakeMesh, "TakeSphere": D.TakeSphere, "TakeLight": D.TakeLight, "TakeCamera": D.TakeCamera,
         "TakeSceneDesc": D.TakeSceneDesc, "TakeBuildOpts": D.TakeBuildOpts, "TakeRenderOpts": D.TakeRenderOpts,
         "TakeRayF": D.TakeRayF, "TakeRayD": D.TakeRayD, "TakeHitF": D.TakeHitF, "TakeHitD": D.TakeHitD,
-        "TakeCounters": D.TakeCounters, "TakeInstance": D.TakeInstance,
+        "TakeCounters": D.TakeCounters, "TakeInstance": D.TakeInstance, "TakePlyLayout": D.TakePlyLayout,
     }
     prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "take_hip.h"', "int main(void){"]
     for n, cls in fields.items():

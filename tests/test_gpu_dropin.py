@@ -93,3 +93,43 @@ def test_python_main_writes_the_same_exr_as_the_reference_binary(tmp_path, monke
         for c in ("B", "G", "R"):
             assert np.array_equal(ours[c].view(np.uint16), ref[c].view(np.uint16)), c
     assert R.render([]).shape == (0, 0, 3)  # src/render.cpp:10-12
+
+
+@pytest.mark.gpu
+def test_cli_reads_ply_on_the_device_and_leaves_big_endian_files_to_the_reference_parser(tmp_path):
+    """take_gpu links take_amd/host/parse_ply_hip.cpp in place of the reference's parse_ply.cpp: little-endian files
+    are decoded on the GPU; a big-endian file — same numbers, bytes swapped — goes to the reference's own parser
+    (compiled in as parse_ply_host).  Both routes must fill the same TriangleMesh: same image, bit for bit.
+    (ascii files are no test case: the reference's vendored tinyply throws "unexpected EOF" on an ascii face list.)"""
+    if not os.path.exists(CLI):
+        pytest.skip("oracle/_ref/take_gpu was not built (needs the reference sources: authoring container)")
+    import shutil
+
+    from oracle import ply as oply
+
+    scenes = os.path.join(GOLD, "scenes")
+    images = {}
+    for kind in ("little", "big"):
+        d = tmp_path / kind
+        d.mkdir()
+        shutil.copy(os.path.join(scenes, "soup1k.xml"), d / "soup1k.xml")
+        data = open(os.path.join(scenes, "soup1k.ply"), "rb").read()
+        if kind == "big":
+            elements, off = oply.read_header(data)
+            (vn, vc, vp), (fn, fc, fp) = elements
+            assert (vn, fn) == ("vertex", "face") and fp[0][1] == ("u1", "<i4")
+            vert = np.frombuffer(data, np.dtype([(n, t) for n, t in vp]), vc, off)
+            face = np.frombuffer(data, np.dtype([("n", "u1"), ("i", "<i4", 3)]), fc, off + vert.nbytes)
+            data = (data[:off].replace(b"binary_little_endian", b"binary_big_endian") +
+                    vert.astype([(n, ">f4") for n, _ in vp]).tobytes() + face.astype([("n", "u1"), ("i", ">i4", 3)]).tobytes())
+        (d / "soup1k.ply").write_bytes(data)
+        pfm = str(d / "out.pfm")
+        r = run_cli(str(d / "soup1k.xml"), str(d), 5, {"TAKE_HIP_DUMP_PFM": pfm, "TAKE_HIP_SEED": "3"})
+        assert r.returncode == 0, r.stderr[-2000:]
+        images[kind] = read_pfm(pfm)
+    assert np.array_equal(images["little"], images["big"]) and images["little"].mean() > 0.01
+    sd = golden_scene("soup1k")
+    sc = capi.Scene(sd, precision=D.TAKE_PRECISION_F32)
+    want = sc.render(spp=sd.spp, max_depth=5, seed=3)
+    sc.close()
+    assert np.array_equal(images["little"], want)
