@@ -91,8 +91,6 @@ def parse_args():
     args.width = dw if args.width is None else args.width
     args.height = dh if args.height is None else args.height
     args.spp = ds if args.spp is None else args.spp
-    if args.instanced and not args.flatten and args.precision == "mixed":
-        args.precision = "f32"  # (mixed precision covers one-level scenes; two-level scenes run the f32 path)
     return args
 
 

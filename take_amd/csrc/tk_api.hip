@@ -1331,8 +1331,6 @@ int take_hip_scene_create(const TakeSceneDesc *desc, const TakeBuildOpts *opts, 
     if (opts) o = *opts;
     if (o.precision != TAKE_PRECISION_F32 && o.precision != TAKE_PRECISION_F64 && o.precision != TAKE_PRECISION_MIXED)
         return fail(TAKE_E_INVALID, "unknown precision");
-    if (o.precision == TAKE_PRECISION_MIXED && desc->n_instances > 0)
-        return fail(TAKE_E_INVALID, "mixed precision: one-level scenes only");
     if (o.builder < TAKE_BUILDER_AUTO || o.builder > TAKE_BUILDER_HOST_SAH) return fail(TAKE_E_INVALID, "unknown builder");
     TakeScene *ts = new (std::nothrow) TakeScene();
     if (!ts) return fail(TAKE_E_NOMEM, "out of host memory");

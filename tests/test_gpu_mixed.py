@@ -86,3 +86,15 @@ def test_mixed_scene_group_equals_single_scene():
     finally:
         g.close()
     assert np.array_equal(got, want)
+
+
+def test_mixed_on_an_instanced_scene():
+    """two-level scenes (TakeInstance): the conversion hands over rays, not hits, so the f32 rounds traverse the f32
+    twin of the same two-level tree.  All rounds exact = the f64 render; the default = closer to it than the f32 path."""
+    sd = scenes.instanced_scene(60, 400, 160, 96, spp=8)
+    ref = _render(sd, D.TAKE_PRECISION_F64, 8, 12, 5)
+    assert np.array_equal(_render(sd, D.TAKE_PRECISION_MIXED, 8, 12, 5, exact=14), ref)
+    e32 = rmse(_render(sd, D.TAKE_PRECISION_F32, 8, 12, 5), ref)
+    emx = rmse(_render(sd, D.TAKE_PRECISION_MIXED, 8, 12, 5), ref)
+    print("instanced: f32", e32, "mixed", emx)
+    assert 0 < emx < 0.7 * e32
