@@ -172,3 +172,39 @@ def test_every_mesh_of_a_golden_scene_from_ply(name, builder, precision):
         a.close(), b.close()
         for dm in dms:
             dm.close()
+
+
+def test_empty_elements_decode_to_empty_arrays():
+    hdr = ("ply\nformat binary_little_endian 1.0\nelement vertex {nv}\nproperty float x\nproperty float y\nproperty float z\n"
+           "element face 0\nproperty list uchar int vertex_indices\nend_header\n")
+    m = capi.DeviceMesh(hdr.format(nv=0).encode())
+    assert (m.n_vertices, m.n_faces) == (0, 0)
+    got = m.download()
+    assert got.positions.shape == (0, 3) and got.indices.shape == (0, 3)
+    m.close()
+    pts = np.arange(12, dtype="<f4")
+    m = capi.DeviceMesh(hdr.format(nv=4).encode() + pts.tobytes())
+    got = m.download()
+    assert np.array_equal(got.positions, pts.reshape(4, 3).astype(np.float64)) and got.indices.shape == (0, 3)
+    m.close()
+    m.close()  # (idempotent)
+
+
+def test_device_mesh_in_a_scene_group():
+    """the shards of a group are replicas of the first scene: a device-decoded mesh goes in like a host one"""
+    from helpers import golden_scene
+
+    sd = golden_scene("meshlight")
+    dms = [capi.DeviceMesh(mesh_to_ply(m), material_id=m.material_id) for m in sd.meshes]
+    sd_dev = copy.copy(sd)
+    sd_dev.meshes = list(dms)
+    sd_host = copy.copy(sd)
+    sd_host.meshes = [dm.download() for dm in dms]
+    one = capi.Scene(sd_host, precision=D.TAKE_PRECISION_F32)
+    grp = capi.SceneGroup(sd_dev, [0, 0, 0], precision=D.TAKE_PRECISION_F32)
+    try:
+        assert np.array_equal(grp.render(spp=4, max_depth=6, seed=9), one.render(spp=4, max_depth=6, seed=9))
+    finally:
+        one.close(), grp.close()
+        for dm in dms:
+            dm.close()
