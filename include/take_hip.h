@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TAKE_HIP_ABI_VERSION 5 /* 2: TakeSceneDesc.instances, TakeRenderOpts.integrator (was reserved); 3: take_hip_render_accumulate; 4: TAKE_PRECISION_MIXED, TakeRenderOpts.exact_bounces; 5: TakeMesh.flags (was reserved), take_hip_mesh_from_ply */
+#define TAKE_HIP_ABI_VERSION 5 /* 2: TakeSceneDesc.instances, TakeRenderOpts.integrator (was reserved); 3: take_hip_render_accumulate; 4: TAKE_PRECISION_MIXED, TakeRenderOpts.exact_bounces; 5: TakeMesh.flags (was reserved), take_hip_mesh_from_ply / _from_serialized */
 
 /* error codes */
 #define TAKE_OK 0
@@ -414,6 +414,16 @@ int take_hip_mesh_from_ply(const void *file_bytes, size_t n_bytes, const double 
 /* the same on a file (memory-mapped, so the body is read once, by the copy to the device) */
 int take_hip_mesh_from_ply_file(const char *path, const double *to_world, const double *inv_to_world,
                                 int32_t material_id, TakeMesh *out);
+/* Mitsuba's serialized mesh format — replaces `TriangleMesh parse_serialized(filename, shape_index, to_world)`
+ * (src/parse/parse_serialized.cpp:174-256).  The zlib stream is inflated on the host (a serial job) in ONE pass into one
+ * buffer — the reference pulls it through ZStream::read three scalars per vertex — and the blocks (positions, normals,
+ * uvs, [colours: skipped], index triples; float or double by EDoublePrecision) are decoded on the device by the kernels
+ * of the PLY path, with the same transforms.  Versions 3 and 4, any sub-mesh (`shape_index`, offset table at the end of
+ * the file: skip_to_idx, :117-133).  Arrays bit-identical to the reference's. */
+int take_hip_mesh_from_serialized(const void *file_bytes, size_t n_bytes, int32_t shape_index, const double *to_world,
+                                  const double *inv_to_world, int32_t material_id, TakeMesh *out);
+int take_hip_mesh_from_serialized_file(const char *path, int32_t shape_index, const double *to_world,
+                                       const double *inv_to_world, int32_t material_id, TakeMesh *out);
 /* copy a device-array mesh to host arrays the caller sized from n_vertices / n_faces (NULL = skip that array) */
 int take_hip_mesh_download(const TakeMesh *mesh, double *positions, int32_t *indices, double *normals, double *uvs);
 int take_hip_mesh_release(TakeMesh *mesh);

@@ -552,6 +552,77 @@ def make_ply():
         print(f"ply/{name}: {int(out[0])} vertices, {int(out[1])} faces, normals {int(out[2])}, uvs {int(out[3])}")
 
 
+def serialized_blob(version, flags, name, pos, nrm, uv, col, faces):
+    """one sub-mesh of Mitsuba's serialized format: [u16 magic][u16 version][zlib: flags, (v4: name NUL), nv, nf, blocks]"""
+    import zlib
+
+    t = "<f8" if flags & 0x2000 else "<f4"
+    body = struct.pack("<I", flags)
+    if version == 4:
+        body += name.encode() + b"\0"
+    body += struct.pack("<QQ", len(pos), len(faces)) + np.asarray(pos, t).tobytes()
+    if flags & 0x0001:
+        body += np.asarray(nrm, t).tobytes()
+    if flags & 0x0002:
+        body += np.asarray(uv, t).tobytes()
+    if flags & 0x0008:
+        body += np.asarray(col, t).tobytes()
+    body += np.asarray(faces, "<i4").tobytes()
+    return struct.pack("<HH", 0x041C, version) + zlib.compress(body, 6)
+
+
+def write_serialized(path, version, blobs):
+    """the sub-meshes back to back, then their offsets (u64 in version 4, u32 in version 3) and the u32 count"""
+    offs, data = [], b""
+    for b in blobs:
+        offs.append(len(data))
+        data += b
+    data += b"".join(struct.pack("<Q" if version == 4 else "<I", o) for o in offs) + struct.pack("<I", len(blobs))
+    with open(path, "wb") as f:
+        f.write(data)
+
+
+def serialized_cases():
+    """name -> (version, [blob kwargs], [(shape_index, to_world)])"""
+    rng = np.random.default_rng(777)
+
+    def geo(nv, nf):
+        return dict(pos=rng.uniform(-2, 2, (nv, 3)), nrm=rng.normal(size=(nv, 3)), uv=rng.uniform(0, 1, (nv, 2)),
+                    col=rng.uniform(0, 1, (nv, 3)), faces=rng.integers(0, nv, (nf, 3)))
+
+    eye = np.eye(4)
+    aff = np.array([[0.0, -1.5, 0.0, 0.5], [2.0, 0.0, 0.0, -1.0], [0.0, 0.0, 0.75, 3.0], [0.0, 0.0, 0.0, 1.0]])
+    aff[:3, :3] = aff[:3, :3] @ np.array([[np.cos(0.4), 0, np.sin(0.4)], [0, 1, 0], [-np.sin(0.4), 0, np.cos(0.4)]])
+    proj = aff.copy()
+    proj[3] = (0.02, 0.01, -0.03, 0.9)
+    g = geo(150, 220)
+    g["nrm"][5] = 0.0  # normalize() returns the zero vector
+    return {
+        "v4_f32_three_meshes": (4, [dict(flags=0x1000, name="plain", **geo(120, 200)),
+                                    dict(flags=0x1000 | 0x0001 | 0x0002, name="normals and uvs", **geo(257, 300)),
+                                    dict(flags=0x1000 | 0x0001 | 0x0002 | 0x0008 | 0x0010, name="", **geo(64, 99))],
+                                [(0, eye), (1, aff), (2, proj)]),
+        "v3_f64_two_meshes": (3, [dict(flags=0x2000 | 0x0002 | 0x0008, name="ignored", **geo(90, 131)),
+                                  dict(flags=0x2000 | 0x0001, name="ignored", **g)], [(0, aff), (1, proj)]),
+    }
+
+
+def make_serialized():
+    """tests/golden/serialized/: Mitsuba-serialized files (versions 3 and 4, float and double, every block combination,
+    several sub-meshes) and the TriangleMesh arrays the reference's own parse_serialized made of each sub-mesh"""
+    d = os.path.join(GOLD, "serialized")
+    os.makedirs(d, exist_ok=True)
+    for name, (version, blobs, picks) in serialized_cases().items():
+        path = os.path.join(d, name + ".serialized")
+        write_serialized(path, version, [serialized_blob(version, **b) for b in blobs])
+        for idx, xf in picks:
+            key = f"{name}_{idx}"
+            np.asarray(xf, "<f8").reshape(-1).tofile(os.path.join(d, key + "_xform.f64"))
+            run("serialized", path, idx, os.path.join(d, key + "_xform.f64"), os.path.join(d, key + "_mesh.f64"))
+            out = np.fromfile(os.path.join(d, key + "_mesh.f64"), "<f8")
+            print(f"serialized/{key}: {int(out[0])} vertices, {int(out[1])} faces, normals {int(out[2])}, uvs {int(out[3])}")
+
+
 def main():
     if not os.path.exists(HARNESS):
         raise SystemExit("oracle/_ref/ref_harness missing: run `make -C oracle ref` (needs /root/reference)")
@@ -566,6 +637,9 @@ def main():
         return
     if sys.argv[1:] == ["ply"]:
         make_ply()
+        return
+    if sys.argv[1:] == ["serialized"]:
+        make_serialized()
         return
     man = {}
     names = make_scene_files()

@@ -31,6 +31,7 @@
 #include "parallel.h"
 #include "parse/parse_ply.h"
 #include "parse/parse_scene.h"
+#include "parse/parse_serialized.h"
 #include "render.h"
 #include "scene.h"
 
@@ -165,6 +166,37 @@ int main(int argc, char **argv) {
         for (auto &v : mesh.normals) push3(o, v);
         for (auto &v : mesh.uvs) o.push_back(v.x), o.push_back(v.y);
         write_f64(argv[4], o);
+        return 0;
+    }
+    if (cmd == "serialized") {
+        // serialized <mesh.serialized> <shape_index> <in.f64: to_world> <out.f64>   the reference's own parse_serialized
+        // (src/parse/parse_serialized.cpp:174-256); out as in `ply`
+        auto in = read_f64(argv[4]);
+        Matrix4x4 m;
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) m(i, j) = in[4 * i + j];
+        TriangleMesh mesh = parse_serialized(argv[2], atoi(argv[3]), m);
+        std::vector<double> o;
+        o.push_back((double)mesh.positions.size());
+        o.push_back((double)mesh.indices.size());
+        o.push_back(mesh.normals.empty() ? 0.0 : 1.0);
+        o.push_back(mesh.uvs.empty() ? 0.0 : 1.0);
+        const Matrix4x4 inv = inverse(m);
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) o.push_back(inv(i, j));
+        for (auto &v : mesh.positions) push3(o, v);
+        for (auto &f : mesh.indices) o.push_back(f[0]), o.push_back(f[1]), o.push_back(f[2]);
+        for (auto &v : mesh.normals) push3(o, v);
+        for (auto &v : mesh.uvs) o.push_back(v.x), o.push_back(v.y);
+        write_f64(argv[5], o);
+        return 0;
+    }
+    if (cmd == "serialized_time") {
+        // serialized_time <mesh.serialized>   seconds the reference's parse_serialized takes on this host
+        const auto t0 = std::chrono::steady_clock::now();
+        TriangleMesh mesh = parse_serialized(argv[2], 0, Matrix4x4::identity());
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("%.6f %zu %zu\n", s, mesh.positions.size(), mesh.indices.size());
         return 0;
     }
     if (cmd == "ply_time") {

@@ -23,7 +23,8 @@ EXPORTS = [
     "take_hip_set_instrumentation", "take_hip_scene_stats", "take_hip_debug_table",
     "take_hip_group_create", "take_hip_group_destroy", "take_hip_group_render", "take_hip_group_render_device",
     "take_hip_group_size", "take_hip_group_get_counters", "take_hip_pack_exr_scanlines", "take_hip_render_exr_scanlines",
-    "take_hip_ply_layout", "take_hip_mesh_from_ply", "take_hip_mesh_from_ply_file", "take_hip_mesh_download", "take_hip_mesh_release",
+    "take_hip_ply_layout", "take_hip_mesh_from_ply", "take_hip_mesh_from_ply_file",
+    "take_hip_mesh_from_serialized", "take_hip_mesh_from_serialized_file", "take_hip_mesh_download", "take_hip_mesh_release",
 ]
 
 
@@ -81,6 +82,8 @@ def lib():
         L.take_hip_ply_layout.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(D.TakePlyLayout)]
         L.take_hip_mesh_from_ply.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(D.TakeMesh)]
         L.take_hip_mesh_from_ply_file.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(D.TakeMesh)]
+        L.take_hip_mesh_from_serialized.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(D.TakeMesh)]
+        L.take_hip_mesh_from_serialized_file.argtypes = [C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(D.TakeMesh)]
         L.take_hip_mesh_download.argtypes = [C.POINTER(D.TakeMesh), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.take_hip_mesh_release.argtypes = [C.POINTER(D.TakeMesh)]
         _LIB = L
@@ -106,12 +109,15 @@ def ply_layout(data):
 
 
 class DeviceMesh:
-    """A triangle mesh decoded from a binary PLY file ON the device (take_hip_mesh_from_ply: replaces the reference's
-    parse_ply, src/parse/parse_ply.cpp:9-123).  The arrays are device memory owned by the library; put the object into
-    SceneData.meshes like a scene.Mesh.  `source`: a path or the file's bytes.  to_world: 4x4 (the reference's Matrix4x4);
-    inv_to_world: the caller's inverse of it (the reference passes its own `inverse(to_world)`), default numpy's."""
+    """A triangle mesh decoded from a binary PLY file or a Mitsuba `.serialized` file ON the device
+    (take_hip_mesh_from_ply / _from_serialized: replace the reference's parse_ply, src/parse/parse_ply.cpp:9-123, and
+    parse_serialized, src/parse/parse_serialized.cpp:174-256).  The arrays are device memory owned by the library; put the
+    object into SceneData.meshes like a scene.Mesh.  `source`: a path or the file's bytes; the format is told from the
+    first bytes (`ply` / anything else = serialized, whose sub-mesh `shape_index` picks).  to_world: 4x4 (the
+    reference's Matrix4x4); inv_to_world: the caller's inverse of it (the reference passes its own
+    `inverse(to_world)`), default numpy's."""
 
-    def __init__(self, source, material_id=0, to_world=None, inv_to_world=None):
+    def __init__(self, source, material_id=0, to_world=None, inv_to_world=None, shape_index=0):
         self.c = D.TakeMesh()
         xw = xi = None
         if to_world is not None:
@@ -121,9 +127,17 @@ class DeviceMesh:
         b = None if xi is None else xi.ctypes.data
         if isinstance(source, (bytes, bytearray, memoryview)):
             buf = bytes(source)
-            _check(lib().take_hip_mesh_from_ply(buf, len(buf), a, b, int(material_id), C.byref(self.c)))
+            if buf[:3] == b"ply":
+                _check(lib().take_hip_mesh_from_ply(buf, len(buf), a, b, int(material_id), C.byref(self.c)))
+            else:
+                _check(lib().take_hip_mesh_from_serialized(buf, len(buf), int(shape_index), a, b, int(material_id), C.byref(self.c)))
         else:
-            _check(lib().take_hip_mesh_from_ply_file(os.fsencode(source), a, b, int(material_id), C.byref(self.c)))
+            with open(source, "rb") as f:
+                is_ply = f.read(3) == b"ply"
+            if is_ply:
+                _check(lib().take_hip_mesh_from_ply_file(os.fsencode(source), a, b, int(material_id), C.byref(self.c)))
+            else:
+                _check(lib().take_hip_mesh_from_serialized_file(os.fsencode(source), int(shape_index), a, b, int(material_id), C.byref(self.c)))
         self.material_id = int(material_id)
 
     n_vertices = property(lambda self: int(self.c.n_vertices))

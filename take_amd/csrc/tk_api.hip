@@ -17,6 +17,8 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <memory>
+#include <zlib.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -1192,12 +1194,103 @@ void fill_layout(const ply::Layout &L, TakePlyLayout *o) {
     o->header_bytes = L.header_bytes;
 }
 
+// a file, memory-mapped read-only (the body is read once: by the copy to the device, or by the inflater)
+struct MappedFile {
+    void *p = nullptr;
+    size_t n = 0;
+    std::string err;
+    explicit MappedFile(const char *path) {
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) {
+            err = std::string("cannot open ") + path;
+            return;
+        }
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || sb.st_size <= 0) {
+            close(fd);
+            err = std::string("cannot read ") + path;
+            return;
+        }
+        void *q = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (q == MAP_FAILED) {
+            err = std::string("cannot map ") + path;
+            return;
+        }
+        (void)madvise(q, (size_t)sb.st_size, MADV_SEQUENTIAL);
+        p = q, n = (size_t)sb.st_size;
+    }
+    ~MappedFile() {
+        if (p) munmap(p, n);
+    }
+    MappedFile(const MappedFile &) = delete;
+    MappedFile &operator=(const MappedFile &) = delete;
+};
+
 void free_mesh_arrays(TakeMesh *m) {
     if (m->positions) (void)hipFree(const_cast<double *>(m->positions));
     if (m->indices) (void)hipFree(const_cast<int32_t *>(m->indices));
     if (m->normals) (void)hipFree(const_cast<double *>(m->normals));
     if (m->uvs) (void)hipFree(const_cast<double *>(m->uvs));
     std::memset(m, 0, sizeof(*m));
+}
+
+// body (host) -> HBM, then the two decode kernels (tk_ply.h); D's offsets are relative to `host_body`
+int decode_mesh_body(const uint8_t *host_body, const ply::Layout &D, const double *to_world, const double *inv_to_world,
+                     int32_t material_id, const char *what, TakeMesh *out) {
+    ply::Mat4 X, Xi;
+    static const double I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::memcpy(X.m, to_world ? to_world : I, sizeof(I));
+    std::memcpy(Xi.m, inv_to_world ? inv_to_world : I, sizeof(I));
+    if (to_world && !inv_to_world && D.nrm_type != ply::T_NONE)
+        return fail(TAKE_E_INVALID, "the file has normals: pass inverse(to_world) along with to_world");
+    DevBuf<uint8_t> body;
+    DevBuf<int32_t> status;
+    TakeMesh m{};
+    m.n_vertices = D.n_vertices, m.n_faces = D.n_faces, m.material_id = material_id, m.flags = TAKE_MESH_DEVICE_ARRAYS;
+    auto bail = [&](int rc) {
+        body.release(), status.release();
+        free_mesh_arrays(&m);
+        return rc;
+    };
+    auto dmalloc = [&](auto *&p, size_t count) -> bool {
+        void *q = nullptr;
+        if (count == 0) return true;
+        if (inject_alloc_failure() || hipMalloc(&q, count * sizeof(*p)) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        p = (std::remove_reference_t<decltype(p)>)q;
+        return true;
+    };
+    double *pos = nullptr, *nrm = nullptr, *uv = nullptr;
+    int32_t *idx = nullptr;
+    const bool ok = body.alloc((size_t)std::max<int64_t>(D.end_off, 1)) == hipSuccess && status.alloc(1) == hipSuccess &&
+                    dmalloc(pos, 3 * (size_t)D.n_vertices) && dmalloc(idx, 3 * (size_t)D.n_faces) &&
+                    (D.nrm_type == ply::T_NONE || dmalloc(nrm, 3 * (size_t)D.n_vertices)) &&
+                    (D.uv_type == ply::T_NONE || dmalloc(uv, 2 * (size_t)D.n_vertices));
+    m.positions = pos, m.indices = idx, m.normals = nrm, m.uvs = uv;
+    if (!ok) return bail(fail(TAKE_E_NOMEM, "out of device memory for a " + std::to_string(D.n_faces) + "-face " + what + " mesh"));
+    {
+        PinnedUploads pin;
+        hipError_t e = pin.copy(body.p, host_body, (size_t)D.end_off);
+        if (e == hipSuccess) e = hipMemsetAsync(status.p, 0, sizeof(int32_t), pin.stream);
+        constexpr int BLK = 256;
+        if (e == hipSuccess && D.n_vertices > 0)
+            hipLaunchKernelGGL(ply::k_ply_vertices, dim3((unsigned)((D.n_vertices + BLK - 1) / BLK)), dim3(BLK), 0, pin.stream, body.p, D, X, Xi, pos, nrm, uv);
+        if (e == hipSuccess && D.n_faces > 0)
+            hipLaunchKernelGGL(ply::k_ply_faces, dim3((unsigned)((D.n_faces + BLK - 1) / BLK)), dim3(BLK), 0, pin.stream, body.p, D, idx, status.p);
+        if (e == hipSuccess) e = hipGetLastError();
+        int32_t st = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&st, status.p, sizeof(st), hipMemcpyDeviceToHost, pin.stream);
+        if (e == hipSuccess) e = pin.finish();
+        if (e != hipSuccess) return bail(fail(TAKE_E_DEVICE, std::string(what) + " decode: " + hipGetErrorString(e)));
+        if (st & 1) return bail(fail(TAKE_E_INVALID, std::string("a face of the ") + what + " file is not a triangle (the reference reads three indices per face)"));
+        if (st & 2) return bail(fail(TAKE_E_INVALID, std::string("a face of the ") + what + " file indexes past its vertex array"));
+    }
+    body.release(), status.release();
+    *out = m;
+    return TAKE_OK;
 }
 }  // namespace
 
@@ -1225,82 +1318,116 @@ int take_hip_mesh_from_ply(const void *file_bytes, size_t n_bytes, const double 
     if (!err.empty()) return fail(TAKE_E_INVALID, err);
     const int nd = check_device();
     if (nd < 0) return nd;
-    ply::Mat4 X, Xi;
-    static const double I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    std::memcpy(X.m, to_world ? to_world : I, sizeof(I));
-    std::memcpy(Xi.m, inv_to_world ? inv_to_world : I, sizeof(I));
-    if (to_world && !inv_to_world && L.nrm_type != ply::T_NONE)
-        return fail(TAKE_E_INVALID, "the file has normals: pass inverse(to_world) along with to_world");
     // the body as it lies in the file: one copy, from the first to the last byte the two elements span
     const int64_t lo = std::min(L.vertex_off, L.face_off);
-    DevBuf<uint8_t> body;
-    DevBuf<int32_t> status;
-    TakeMesh m{};
-    m.n_vertices = L.n_vertices, m.n_faces = L.n_faces, m.material_id = material_id, m.flags = TAKE_MESH_DEVICE_ARRAYS;
-    auto bail = [&](int rc) {
-        body.release(), status.release();
-        free_mesh_arrays(&m);
-        return rc;
-    };
-    auto dmalloc = [&](auto *&p, size_t count) -> bool {
-        void *q = nullptr;
-        if (count == 0) return true;
-        if (inject_alloc_failure() || hipMalloc(&q, count * sizeof(*p)) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
-        p = (std::remove_reference_t<decltype(p)>)q;
-        return true;
-    };
-    double *pos = nullptr, *nrm = nullptr, *uv = nullptr;
-    int32_t *idx = nullptr;
-    const bool ok = body.alloc((size_t)std::max<int64_t>(L.end_off - lo, 1)) == hipSuccess && status.alloc(1) == hipSuccess &&
-                    dmalloc(pos, 3 * (size_t)L.n_vertices) && dmalloc(idx, 3 * (size_t)L.n_faces) &&
-                    (L.nrm_type == ply::T_NONE || dmalloc(nrm, 3 * (size_t)L.n_vertices)) &&
-                    (L.uv_type == ply::T_NONE || dmalloc(uv, 2 * (size_t)L.n_vertices));
-    m.positions = pos, m.indices = idx, m.normals = nrm, m.uvs = uv;
-    if (!ok) return bail(fail(TAKE_E_NOMEM, "out of device memory for a " + std::to_string(L.n_faces) + "-face PLY mesh"));
-    {
-        PinnedUploads pin;
-        hipError_t e = pin.copy(body.p, (const uint8_t *)file_bytes + lo, (size_t)(L.end_off - lo));
-        if (e == hipSuccess) e = hipMemsetAsync(status.p, 0, sizeof(int32_t), pin.stream);
-        ply::Layout D = L;  // offsets relative to the copied span
-        D.vertex_off -= lo, D.face_off -= lo;
-        constexpr int BLK = 256;
-        if (e == hipSuccess && L.n_vertices > 0)
-            hipLaunchKernelGGL(ply::k_ply_vertices, dim3((unsigned)((L.n_vertices + BLK - 1) / BLK)), dim3(BLK), 0, pin.stream, body.p, D, X, Xi, pos, nrm, uv);
-        if (e == hipSuccess && L.n_faces > 0)
-            hipLaunchKernelGGL(ply::k_ply_faces, dim3((unsigned)((L.n_faces + BLK - 1) / BLK)), dim3(BLK), 0, pin.stream, body.p, D, idx, status.p);
-        if (e == hipSuccess) e = hipGetLastError();
-        int32_t st = 0;
-        if (e == hipSuccess) e = hipMemcpyAsync(&st, status.p, sizeof(st), hipMemcpyDeviceToHost, pin.stream);
-        if (e == hipSuccess) e = pin.finish();
-        if (e != hipSuccess) return bail(fail(TAKE_E_DEVICE, std::string("PLY decode: ") + hipGetErrorString(e)));
-        if (st & 1) return bail(fail(TAKE_E_INVALID, "a face of the PLY file is not a triangle (the reference reads three indices per face)"));
-        if (st & 2) return bail(fail(TAKE_E_INVALID, "a face of the PLY file indexes past its vertex array"));
+    ply::Layout D = L;  // offsets relative to the copied span
+    D.vertex_off -= lo, D.face_off -= lo, D.nrm_base -= lo, D.uv_base -= lo, D.end_off -= lo;
+    return decode_mesh_body((const uint8_t *)file_bytes + lo, D, to_world, inv_to_world, material_id, "PLY", out);
+}
+
+// ---- Mitsuba serialized meshes (src/parse/parse_serialized.cpp:174-256): inflate on the host, decode on the device --
+namespace {
+struct Inflater {
+    z_stream z{};
+    bool open = false;
+    const uint8_t *src;
+    size_t left;
+    Inflater(const uint8_t *p, size_t n) : src(p), left(n) {
+        open = inflateInit2(&z, 15) == Z_OK;  // (windowBits 15: parse_serialized.cpp:47)
     }
-    body.release(), status.release();
-    *out = m;
-    return TAKE_OK;
+    ~Inflater() {
+        if (open) inflateEnd(&z);
+    }
+    // exactly `size` inflated bytes into dst, or what is wrong (the messages of ZStream::read, parse_serialized.cpp:60-104)
+    const char *read(void *dst, size_t size) {
+        uint8_t *out = (uint8_t *)dst;
+        while (size > 0) {
+            if (z.avail_in == 0) {
+                const size_t take = std::min<size_t>(left, (size_t)1 << 30);
+                if (take == 0) return "read less data than expected";
+                z.next_in = const_cast<uint8_t *>(src), z.avail_in = (uInt)take;
+                src += take, left -= take;
+            }
+            const size_t want = std::min<size_t>(size, (size_t)1 << 30);
+            z.next_out = out, z.avail_out = (uInt)want;
+            const int rv = inflate(&z, Z_NO_FLUSH);
+            if (rv == Z_STREAM_ERROR) return "inflate(): stream error";
+            if (rv == Z_NEED_DICT) return "inflate(): need dictionary";
+            if (rv == Z_DATA_ERROR) return "inflate(): data error";
+            if (rv == Z_MEM_ERROR) return "inflate(): memory error";
+            const size_t got = want - z.avail_out;
+            out += got, size -= got;
+            if (size > 0 && rv == Z_STREAM_END) return "inflate(): attempting to read past the end of the stream";
+            if (got == 0 && rv == Z_BUF_ERROR && left == 0 && z.avail_in == 0) return "read less data than expected";
+        }
+        return nullptr;
+    }
+};
+}  // namespace
+
+int take_hip_mesh_from_serialized(const void *file_bytes, size_t n_bytes, int32_t shape_index, const double *to_world,
+                                  const double *inv_to_world, int32_t material_id, TakeMesh *out) {
+    if (!file_bytes || !out) return fail(TAKE_E_INVALID, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    const uint8_t *f = (const uint8_t *)file_bytes;
+    if (n_bytes < 4) return fail(TAKE_E_INVALID, "not a serialized mesh file: shorter than its header");
+    uint16_t version = 0;
+    std::memcpy(&version, f + 2, 2);  // (the magic number in front of it is ignored: parse_serialized.cpp:178)
+    if (version != 3 && version != 4) return fail(TAKE_E_INVALID, "serialized mesh: unknown format version " + std::to_string(version));
+    size_t at = 0;
+    if (shape_index > 0) {  // skip_to_idx (parse_serialized.cpp:117-133): the offset table at the end of the file
+        uint32_t count = 0;
+        std::memcpy(&count, f + n_bytes - 4, 4);
+        const size_t esz = version == 4 ? 8 : 4;
+        if ((uint64_t)shape_index >= count || n_bytes < 4 + esz * (size_t)count)
+            return fail(TAKE_E_INVALID, "serialized mesh: shape index " + std::to_string(shape_index) + " of " + std::to_string(count));
+        uint64_t off = 0;
+        std::memcpy(&off, f + n_bytes - 4 - esz * ((size_t)count - (size_t)shape_index), esz);
+        if (off + 4 > n_bytes) return fail(TAKE_E_INVALID, "serialized mesh: sub-mesh offset past the end of the file");
+        at = (size_t)off;
+    } else if (shape_index < 0) {
+        return fail(TAKE_E_INVALID, "serialized mesh: negative shape index");
+    }
+    Inflater z(f + at + 4, n_bytes - at - 4);
+    if (!z.open) return fail(TAKE_E_DEVICE, "could not initialize zlib");
+    uint32_t flags = 0;
+    uint64_t nv = 0, nf = 0;
+    const char *bad = z.read(&flags, 4);
+    if (!bad && version == 4) {  // the mesh's name, NUL-terminated
+        char c = 1;
+        while (!bad && c != 0) bad = z.read(&c, 1);
+    }
+    if (!bad) bad = z.read(&nv, 8);
+    if (!bad) bad = z.read(&nf, 8);
+    if (bad) return fail(TAKE_E_INVALID, std::string("serialized mesh: ") + bad);
+    if (nv >= ((uint64_t)1 << 31) || nf >= ((uint64_t)1 << 31) / 3) return fail(TAKE_E_INVALID, "serialized mesh too large for 32-bit vertex indices");
+    ply::Layout L;
+    ply::serialized_layout(flags, (int64_t)nv, (int64_t)nf, L);
+    const int nd = check_device();
+    if (nd < 0) return nd;
+    // the blocks, inflated once into one host buffer; the kernels read them where the stream put them
+    std::unique_ptr<uint8_t[]> body(new (std::nothrow) uint8_t[(size_t)std::max<int64_t>(L.end_off, 1)]);
+    if (!body) return fail(TAKE_E_NOMEM, "out of host memory for the inflated mesh");
+    bad = z.read(body.get(), (size_t)L.end_off);
+    if (bad) return fail(TAKE_E_INVALID, std::string("serialized mesh: ") + bad);
+    return decode_mesh_body(body.get(), L, to_world, inv_to_world, material_id, "serialized", out);
 }
 
 int take_hip_mesh_from_ply_file(const char *path, const double *to_world, const double *inv_to_world, int32_t material_id, TakeMesh *out) {
     if (!path || !out) return fail(TAKE_E_INVALID, "null argument");
     std::memset(out, 0, sizeof(*out));
-    const int fd = open(path, O_RDONLY);
-    if (fd < 0) return fail(TAKE_E_INVALID, std::string("cannot open ") + path);
-    struct stat sb;
-    if (fstat(fd, &sb) != 0 || sb.st_size <= 0) {
-        close(fd);
-        return fail(TAKE_E_INVALID, std::string("cannot read ") + path);
-    }
-    void *p = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (p == MAP_FAILED) return fail(TAKE_E_INVALID, std::string("cannot map ") + path);
-    (void)madvise(p, (size_t)sb.st_size, MADV_SEQUENTIAL);
-    const int rc = take_hip_mesh_from_ply(p, (size_t)sb.st_size, to_world, inv_to_world, material_id, out);
-    munmap(p, (size_t)sb.st_size);
-    return rc;
+    MappedFile mf(path);
+    if (!mf.p) return fail(TAKE_E_INVALID, mf.err);
+    return take_hip_mesh_from_ply(mf.p, mf.n, to_world, inv_to_world, material_id, out);
+}
+
+int take_hip_mesh_from_serialized_file(const char *path, int32_t shape_index, const double *to_world, const double *inv_to_world,
+                                       int32_t material_id, TakeMesh *out) {
+    if (!path || !out) return fail(TAKE_E_INVALID, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    MappedFile mf(path);
+    if (!mf.p) return fail(TAKE_E_INVALID, mf.err);
+    return take_hip_mesh_from_serialized(mf.p, mf.n, shape_index, to_world, inv_to_world, material_id, out);
 }
 
 int take_hip_mesh_download(const TakeMesh *m, double *positions, int32_t *indices, double *normals, double *uvs) {

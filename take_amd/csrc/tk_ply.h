@@ -1,4 +1,4 @@
-// PLY -> device mesh arrays ("direct PLY -> device buffers").
+// PLY / serialized -> device mesh arrays ("direct PLY/serialized -> device buffers").
 //
 // What it replaces: src/parse/parse_ply.cpp:9-123 — tinyply reads the file on the host, then four host loops widen
 // x/y/z, u/v, nx/ny/nz to Real, push positions through xform_point(to_world) (src/transform.cpp:79-87), normals through
@@ -41,7 +41,9 @@ struct Layout {
     int32_t pos_type, pos_off[3];  // T_F32 / T_F64 (parse_ply.cpp:39-52 fills positions for these two only)
     int32_t nrm_type, nrm_off[3];  // T_NONE: the file has no nx/ny/nz
     int32_t uv_type, uv_off[2];    // T_NONE: no u/v
-    int32_t count_type, index_type;
+    int64_t nrm_base, uv_base;     // first byte of the rows the normals / uvs are read from, and their strides: the
+    int32_t nrm_stride, uv_stride; // vertex rows in a PLY file (interleaved), blocks of their own in a serialized mesh
+    int32_t count_type, index_type;  // count_type T_NONE: rows of three indices without a count (serialized mesh)
     int32_t list_off;              // byte offset of the list's count inside a face row
     int32_t header_bytes;
 };
@@ -162,6 +164,7 @@ inline std::string parse_header(const uint8_t *p, size_t n, Layout &L) {
                 for (int k = 0; k < 2; k++) L.uv_off[k] = seen[6 + k];
             }
             L.n_vertices = e.count, L.vertex_off = off, L.vertex_stride = stride;
+            L.nrm_base = L.uv_base = off, L.nrm_stride = L.uv_stride = stride;
             off += e.count * (int64_t)stride;
             have_v = true;
         } else if (e.name == "face" && !have_f) {
@@ -200,6 +203,33 @@ inline std::string parse_header(const uint8_t *p, size_t n, Layout &L) {
     if ((uint64_t)L.end_off > n) return "PLY file is shorter than its header says (" + std::to_string(n) + " bytes, need " + std::to_string(L.end_off) + ")";
     if (L.n_vertices >= ((int64_t)1 << 31) || L.n_faces >= ((int64_t)1 << 31) / 3) return "mesh too large for 32-bit vertex indices";
     return "";
+}
+
+// ---- Mitsuba's serialized mesh format (src/parse/parse_serialized.cpp:174-256) ------------------------------------
+// File: per sub-mesh [u16 magic][u16 version 3|4][zlib stream]; at the end of the file one offset per sub-mesh (u64 in
+// version 4, u32 in version 3) and a u32 count (skip_to_idx, parse_serialized.cpp:117-133).  Inflated stream: u32 flags,
+// (version 4: a NUL-terminated name), u64 vertex count, u64 triangle count, then BLOCKS — positions (3 reals per
+// vertex), normals if EHasNormals, uvs (2) if EHasTexcoords, colours (3, ignored) if EHasColors, 3 ints per triangle.
+// Reals are double iff EDoublePrecision is set (parse_serialized.cpp:212: the single-precision flag is not looked at).
+enum SerializedFlags : uint32_t { S_HAS_NORMALS = 0x0001, S_HAS_TEXCOORDS = 0x0002, S_HAS_COLORS = 0x0008, S_DOUBLE = 0x2000 };
+
+// Layout of the blocks behind the counts; offsets are bytes from the first byte of the position block
+inline void serialized_layout(uint32_t flags, int64_t nv, int64_t nf, Layout &L) {
+    std::memset(&L, 0, sizeof(L));
+    const int32_t t = (flags & S_DOUBLE) ? T_F64 : T_F32, sz = type_size(t);
+    int64_t off = 0;
+    L.n_vertices = nv, L.n_faces = nf;
+    L.pos_type = t, L.vertex_off = 0, L.vertex_stride = 3 * sz;
+    for (int k = 0; k < 3; k++) L.pos_off[k] = k * sz, L.nrm_off[k] = k * sz;
+    L.uv_off[0] = 0, L.uv_off[1] = sz;
+    off += nv * 3 * (int64_t)sz;
+    L.nrm_type = L.uv_type = T_NONE;
+    if (flags & S_HAS_NORMALS) L.nrm_type = t, L.nrm_base = off, L.nrm_stride = 3 * sz, off += nv * 3 * (int64_t)sz;
+    if (flags & S_HAS_TEXCOORDS) L.uv_type = t, L.uv_base = off, L.uv_stride = 2 * sz, off += nv * 2 * (int64_t)sz;
+    if (flags & S_HAS_COLORS) off += nv * 3 * (int64_t)sz;
+    L.count_type = T_NONE, L.index_type = T_I32, L.list_off = 0, L.face_off = off, L.face_stride = 12;
+    off += nf * 12;
+    L.end_off = off;
 }
 
 // one scalar of a row, widened to double / narrowed to int32 the way the reference's casts do; rows are not aligned
@@ -249,8 +279,9 @@ __global__ void k_ply_vertices(const uint8_t *file, Layout L, Mat4 X, Mat4 Xi, d
         pos[3 * i + 0] = tx * inv_w, pos[3 * i + 1] = ty * inv_w, pos[3 * i + 2] = tz * inv_w;
     }
     if (nrm) {
-        const double x = load_real(row + L.nrm_off[0], L.nrm_type), y = load_real(row + L.nrm_off[1], L.nrm_type),
-                     z = load_real(row + L.nrm_off[2], L.nrm_type);
+        const uint8_t *nrow = file + L.nrm_base + i * (int64_t)L.nrm_stride;
+        const double x = load_real(nrow + L.nrm_off[0], L.nrm_type), y = load_real(nrow + L.nrm_off[1], L.nrm_type),
+                     z = load_real(nrow + L.nrm_off[2], L.nrm_type);
         const double *m = Xi.m;
         const double nx = m[0] * x + m[4] * y + m[8] * z;
         const double ny = m[1] * x + m[5] * y + m[9] * z;
@@ -261,8 +292,9 @@ __global__ void k_ply_vertices(const uint8_t *file, Layout L, Mat4 X, Mat4 Xi, d
         else nrm[3 * i + 0] = nx * inv_l, nrm[3 * i + 1] = ny * inv_l, nrm[3 * i + 2] = nz * inv_l;
     }
     if (uv) {
-        uv[2 * i + 0] = load_real(row + L.uv_off[0], L.uv_type);
-        uv[2 * i + 1] = load_real(row + L.uv_off[1], L.uv_type);
+        const uint8_t *urow = file + L.uv_base + i * (int64_t)L.uv_stride;
+        uv[2 * i + 0] = load_real(urow + L.uv_off[0], L.uv_type);
+        uv[2 * i + 1] = load_real(urow + L.uv_off[1], L.uv_type);
     }
 }
 
@@ -273,9 +305,9 @@ __global__ void k_ply_faces(const uint8_t *file, Layout L, int32_t *idx, int32_t
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= L.n_faces) return;
     const uint8_t *row = file + L.face_off + i * (int64_t)L.face_stride + L.list_off;
-    const int64_t cnt = load_int(row, L.count_type);
-    int32_t bad = cnt != 3 ? 1 : 0;
-    const int cs = type_size(L.count_type), is = type_size(L.index_type);
+    const bool counted = L.count_type != T_NONE;
+    int32_t bad = (counted && load_int(row, L.count_type) != 3) ? 1 : 0;
+    const int cs = counted ? type_size(L.count_type) : 0, is = type_size(L.index_type);
     for (int k = 0; k < 3; k++) {
         const int32_t v = (int32_t)load_int(row + cs + k * is, L.index_type);
         if (v < 0 || v >= L.n_vertices) bad |= 2;

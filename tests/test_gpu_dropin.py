@@ -133,3 +133,41 @@ def test_cli_reads_ply_on_the_device_and_leaves_big_endian_files_to_the_referenc
     want = sc.render(spp=sd.spp, max_depth=5, seed=3)
     sc.close()
     assert np.array_equal(images["little"], want)
+
+
+@pytest.mark.gpu
+def test_cli_reads_serialized_meshes_on_the_device(tmp_path):
+    """take_gpu links take_amd/host/parse_serialized_hip.cpp in place of the reference's parse_serialized.cpp: the soup of
+    the golden scene, rewritten as sub-mesh 1 of a Mitsuba-serialized file (version 4, float), must give the image of the
+    PLY scene bit for bit — same vertices, same faces, through the other loader"""
+    if not os.path.exists(CLI):
+        pytest.skip("oracle/_ref/take_gpu was not built (needs the reference sources: authoring container)")
+    import struct
+    import zlib
+
+    from oracle import ply as oply
+
+    scenes = os.path.join(GOLD, "scenes")
+    mesh = oply.parse_ply(open(os.path.join(scenes, "soup1k.ply"), "rb").read())
+
+    def sub(pos, faces, name):
+        body = struct.pack("<I", 0x1000) + name + b"\0" + struct.pack("<QQ", len(pos), len(faces))
+        return struct.pack("<HH", 0x041C, 4) + zlib.compress(body + pos.astype("<f4").tobytes() + faces.astype("<i4").tobytes())
+
+    decoy = sub(np.zeros((3, 3)), np.array([[0, 1, 2]]), b"decoy")
+    soup = sub(mesh["positions"], mesh["indices"], b"soup")
+    data = decoy + soup + struct.pack("<QQI", 0, len(decoy), 2)
+    (tmp_path / "soup1k.serialized").write_bytes(data)
+    xml = open(os.path.join(scenes, "soup1k.xml")).read()
+    old = '<shape type="ply"><string name="filename" value="soup1k.ply"/>'
+    assert xml.count(old) == 1
+    xml = xml.replace(old, '<shape type="serialized"><string name="filename" value="soup1k.serialized"/><integer name="shapeIndex" value="1"/>')
+    (tmp_path / "soup1k.xml").write_text(xml)
+    pfm = str(tmp_path / "out.pfm")
+    r = run_cli(str(tmp_path / "soup1k.xml"), str(tmp_path), 5, {"TAKE_HIP_DUMP_PFM": pfm, "TAKE_HIP_SEED": "3"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    sd = golden_scene("soup1k")
+    sc = capi.Scene(sd, precision=D.TAKE_PRECISION_F32)
+    want = sc.render(spp=sd.spp, max_depth=5, seed=3)
+    sc.close()
+    assert np.array_equal(read_pfm(pfm), want)

@@ -54,6 +54,27 @@ for _ in range(3):
     dt = time.time() - t0
     print(f"device decode (mmap -> HBM -> kernels): {dt * 1e3:.1f} ms = {size / dt / 1e9:.1f} GB/s of file", flush=True)
     keep = dm
+# the same mesh as a Mitsuba-serialized file (version 4, float; zlib level 1)
+import struct  # noqa: E402
+import zlib  # noqa: E402
+
+spath = f"/tmp/soup_{n_tris}.serialized"
+body = struct.pack("<I", 0x1000) + b"soup\0" + struct.pack("<QQ", len(host.positions), len(host.indices))
+body += host.positions.astype("<f4").tobytes() + host.indices.astype("<i4").tobytes()
+with open(spath, "wb") as f:
+    f.write(struct.pack("<HH", 0x041C, 4) + zlib.compress(body, 1) + struct.pack("<QI", 0, 1))
+print(f"{spath}: {os.path.getsize(spath) / 1e6:.0f} MB ({len(body) / 1e6:.0f} MB inflated)", flush=True)
+del body
+if os.path.exists(harness):
+    r = subprocess.run([harness, "serialized_time", spath], stdout=subprocess.PIPE, text=True)
+    print("reference parse_serialized (ZStream, three reads per vertex):", r.stdout.strip().split()[0], "s", flush=True)
+for _ in range(2):
+    t0 = time.time()
+    sm = capi.DeviceMesh(spath, material_id=host.material_id)
+    torch.cuda.synchronize()
+    print(f"device decode of the serialized file (one-pass inflate on the host + kernels): {time.time() - t0:.3f} s", flush=True)
+    sm.close()
+os.remove(spath)
 os.environ["TAKE_HIP_VERBOSE"] = "1"
 sd_dev = scenes.soup_scene(8, 64, 64, spp=1)  # (the box + light; the soup mesh is swapped for the device one)
 for label, mesh in (("host arrays", type(host)(host.positions.astype(np.float32).astype(np.float64), host.indices, host.material_id)),
