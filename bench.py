@@ -68,8 +68,8 @@ def parse_args():
                     help="configs[4]: N placements of a T-triangle mesh, mixed BSDFs (e.g. 1000x10000), traversed on two "
                          "levels (TakeInstance: one prototype + N transforms); replaces the soup (not the default workload)")
     ap.add_argument("--flatten", action="store_true",
-                    help="with --instanced: expand the placements to world-space triangles (what the reference's scene "
-                         "model can express; the instanced render is specified to equal it)")
+                    help="with --instanced: scene_create expands the placements to world-space triangles (what the reference's "
+                         "scene model can express; the instanced render is specified to equal it) — 40x the memory, a third faster")
     ap.add_argument("--builder", default="host", choices=["host", "device", "auto"],
                     help="host = binned SAH (default: the best trees); device = records + LBVH built on the GPU (fast "
                          "build, 2-6 %% slower traversal); auto = the library's default (host below 4M shapes)")
@@ -227,7 +227,8 @@ def run_leg(args, sd, precision, steps, warmup, rank, world, backend, spp_total,
     t0 = time.time()
     scene = capi.Scene(sd, precision={"f32": D.TAKE_PRECISION_F32, "f64": D.TAKE_PRECISION_F64, "mixed": D.TAKE_PRECISION_MIXED}[precision],
                        max_leaf_size=args.max_leaf,
-                       builder={"device": D.TAKE_BUILDER_DEVICE_LBVH, "host": D.TAKE_BUILDER_HOST_SAH, "auto": D.TAKE_BUILDER_AUTO}[args.builder])
+                       builder={"device": D.TAKE_BUILDER_DEVICE_LBVH, "host": D.TAKE_BUILDER_HOST_SAH, "auto": D.TAKE_BUILDER_AUTO}[args.builder],
+                       flatten_instances=bool(args.instanced) and args.flatten)
     t_setup = time.time() - t0
     scene.exact_bounces = args.exact_bounces
     stats = scene.stats()
@@ -330,8 +331,8 @@ def main():
     spp_total = args.spp if strong else args.spp * world  # weak scaling: per-GPU samples fixed; configs[3]: total fixed
     if args.instanced:
         n_inst, n_tri = (int(x) for x in args.instanced.split("x"))
-        sd = scenes.instanced_scene(n_inst, n_tri, args.width, args.height, spp=spp_total, max_depth=args.max_depth,
-                                    flatten=args.flatten)
+        # (--flatten: the library expands the placements itself, TakeBuildOpts.instances = TAKE_INSTANCES_FLATTEN)
+        sd = scenes.instanced_scene(n_inst, n_tri, args.width, args.height, spp=spp_total, max_depth=args.max_depth)
         if args.envmap:
             sd.add_envmap(scenes.sky_envmap(2048, 1024))
     else:

@@ -187,14 +187,17 @@ class Scene:
     """A scene resident on the current HIP device: flattened `Scene` + wide BVH in HBM."""
 
     def __init__(self, scene_data, precision=D.TAKE_PRECISION_F32, bvh_threads=0, max_leaf_size=0,
-                 builder=D.TAKE_BUILDER_AUTO, burley_lobes=False):
-        """burley_lobes: the scene's Disney materials (tags 7..11: Lambert clones, as upstream) are rendered with the
+                 builder=D.TAKE_BUILDER_AUTO, burley_lobes=False, flatten_instances=False):
+        """flatten_instances: placements (TakeInstance) are expanded to world-space triangles by scene_create instead of
+        being traversed on two levels (TAKE_INSTANCES_FLATTEN).
+        burley_lobes: the scene's Disney materials (tags 7..11: Lambert clones, as upstream) are rendered with the
         real lobes (tags 12..16, an extension — DESIGN.md §4d)"""
         self.sd = scene_data
         self.precision = precision
         self.dtype = np.float32 if precision == D.TAKE_PRECISION_F32 else np.float64
         desc, keep = scene_data.to_desc()
-        opts = D.TakeBuildOpts(precision, bvh_threads, max_leaf_size, builder, 1 if burley_lobes else 0, 0)
+        opts = D.TakeBuildOpts(precision, bvh_threads, max_leaf_size, builder, 1 if burley_lobes else 0,
+                               D.TAKE_INSTANCES_FLATTEN if flatten_instances else D.TAKE_INSTANCES_TWO_LEVEL)
         h = C.c_void_p()
         _check(lib().take_hip_scene_create(C.byref(desc), C.byref(opts), C.byref(h)))
         self.h = h
@@ -300,12 +303,13 @@ class SceneGroup:
     C++ host uses in place of its thread pool.  `devices`: HIP device per shard; a device may repeat (logical shards)."""
 
     def __init__(self, scene_data, devices, precision=D.TAKE_PRECISION_F32, bvh_threads=0, max_leaf_size=0,
-                 builder=D.TAKE_BUILDER_AUTO, burley_lobes=False):
+                 builder=D.TAKE_BUILDER_AUTO, burley_lobes=False, flatten_instances=False):
         self.sd = scene_data
         self.precision = precision
         self.dtype = np.float32 if precision == D.TAKE_PRECISION_F32 else np.float64
         desc, keep = scene_data.to_desc()
-        opts = D.TakeBuildOpts(precision, bvh_threads, max_leaf_size, builder, 1 if burley_lobes else 0, 0)
+        opts = D.TakeBuildOpts(precision, bvh_threads, max_leaf_size, builder, 1 if burley_lobes else 0,
+                               D.TAKE_INSTANCES_FLATTEN if flatten_instances else D.TAKE_INSTANCES_TWO_LEVEL)
         devs = (C.c_int32 * len(devices))(*devices)
         h = C.c_void_p()
         _check(lib().take_hip_group_create(C.byref(desc), C.byref(opts), len(devices), devs, C.byref(h)))

@@ -77,9 +77,11 @@ class TakeSceneDesc(C.Structure):
 
 class TakeBuildOpts(C.Structure):
     _fields_ = [("precision", C.c_int32), ("bvh_threads", C.c_int32), ("max_leaf_size", C.c_int32),
-                ("builder", C.c_int32), ("burley_lobes", C.c_int32), ("reserved", C.c_int32)]
+                ("builder", C.c_int32), ("burley_lobes", C.c_int32), ("instances", C.c_int32)]
 
 
+TAKE_INSTANCES_TWO_LEVEL = 0    # placements are leaves of a top-level BVH
+TAKE_INSTANCES_FLATTEN = 1      # placements expanded to world-space triangles by scene_create
 TAKE_BUILDER_AUTO = 0          # host SAH below 4M shapes, device LBVH from there on
 TAKE_BUILDER_DEVICE_LBVH = 1
 TAKE_BUILDER_HOST_SAH = 2

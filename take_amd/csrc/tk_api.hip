@@ -342,6 +342,99 @@ int build_bvh_device(SceneT<float> &sc, int max_leaf, bool compressed_ok, bool c
     HIP_TRY(hipGetLastError());
     return TAKE_OK;
 }
+// TAKE_INSTANCES_FLATTEN: the description with every placement expanded to a world-space mesh of its own — the geometry
+// an instanced render is specified to equal (TakeInstance, include/take_hip.h).  Placement i becomes mesh n_meshes + i:
+// positions M[:, :3] p + M[:, 3] and normals n^T L^-1 (not re-normalised: interpolation commutes with the linear map
+// only then; the interpolated normal is normalised at the hit) in double, on `threads` host threads; the prototype's
+// index and uv arrays are shared, not copied.  The shape arrays grow by the placements' faces in placement order, so
+// shape ids are the two-level scene's (n_shapes + faces of the preceding placements + face).
+struct FlattenedInstances {
+    std::vector<TakeMesh> meshes;
+    std::vector<std::vector<double>> arrays;
+    std::vector<int32_t> kind, ref, face, area_light;
+    int expand(TakeSceneDesc &d, int threads) {
+        if (d.n_instances <= 0) return TAKE_OK;
+        if (!d.instances) return fail(TAKE_E_INVALID, "n_instances > 0 but instances is null");
+        int64_t extra = 0;
+        for (int64_t i = 0; i < d.n_instances; i++) {
+            const TakeInstance &in = d.instances[i];
+            if (in.mesh_id < 0 || in.mesh_id >= d.n_meshes) return fail(TAKE_E_INVALID, "instance " + std::to_string(i) + ": bad mesh index");
+            const TakeMesh &m = d.meshes[in.mesh_id];
+            if (m.flags & TAKE_MESH_DEVICE_ARRAYS) return fail(TAKE_E_INVALID, "instance " + std::to_string(i) + ": flattening reads the prototype on the host; it is a device-array mesh");
+            if (m.n_vertices < 0 || m.n_faces < 0 || (m.n_faces > 0 && (!m.positions || !m.indices))) return fail(TAKE_E_INVALID, "instance " + std::to_string(i) + ": bad prototype mesh");
+            if (in.material_id >= d.n_materials) return fail(TAKE_E_INVALID, "instance " + std::to_string(i) + ": bad material index");
+            extra += m.n_faces;
+        }
+        if (d.n_shapes + extra >= ((int64_t)1 << 31) || (int64_t)d.n_meshes + d.n_instances >= ((int64_t)1 << 31))
+            return fail(TAKE_E_INVALID, "flattened scene too large (" + std::to_string(d.n_shapes + extra) + " shapes)");
+        meshes.assign(d.meshes, d.meshes + d.n_meshes);
+        meshes.resize((size_t)d.n_meshes + (size_t)d.n_instances);
+        arrays.resize(2 * (size_t)d.n_instances);
+        std::string err;
+        std::mutex mu;
+        auto work = [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; i++) {
+                const TakeInstance &in = d.instances[i];
+                const TakeMesh &m = d.meshes[in.mesh_id];
+                const double *x = in.xform;
+                const double a00 = x[0], a01 = x[1], a02 = x[2], a10 = x[4], a11 = x[5], a12 = x[6], a20 = x[8], a21 = x[9], a22 = x[10];
+                std::vector<double> &pos = arrays[2 * (size_t)i], &nrm = arrays[2 * (size_t)i + 1];
+                pos.resize(3 * (size_t)m.n_vertices);
+                for (int64_t v = 0; v < m.n_vertices; v++) {
+                    const double px = m.positions[3 * v], py = m.positions[3 * v + 1], pz = m.positions[3 * v + 2];
+                    pos[3 * v + 0] = a00 * px + a01 * py + a02 * pz + x[3];
+                    pos[3 * v + 1] = a10 * px + a11 * py + a12 * pz + x[7];
+                    pos[3 * v + 2] = a20 * px + a21 * py + a22 * pz + x[11];
+                }
+                if (m.normals) {
+                    const double det = a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
+                    if (!(std::fabs(det) > 1e-300)) {
+                        std::lock_guard<std::mutex> lock(mu);
+                        err = "instance " + std::to_string(i) + ": singular transform";
+                        return;
+                    }
+                    const double inv[9] = {(a11 * a22 - a12 * a21) / det, (a02 * a21 - a01 * a22) / det, (a01 * a12 - a02 * a11) / det,
+                                           (a12 * a20 - a10 * a22) / det, (a00 * a22 - a02 * a20) / det, (a02 * a10 - a00 * a12) / det,
+                                           (a10 * a21 - a11 * a20) / det, (a01 * a20 - a00 * a21) / det, (a00 * a11 - a01 * a10) / det};
+                    nrm.resize(3 * (size_t)m.n_vertices);
+                    for (int64_t v = 0; v < m.n_vertices; v++) {
+                        const double nx = m.normals[3 * v], ny = m.normals[3 * v + 1], nz = m.normals[3 * v + 2];
+                        nrm[3 * v + 0] = nx * inv[0] + ny * inv[3] + nz * inv[6];  // (n^T L^-1)
+                        nrm[3 * v + 1] = nx * inv[1] + ny * inv[4] + nz * inv[7];
+                        nrm[3 * v + 2] = nx * inv[2] + ny * inv[5] + nz * inv[8];
+                    }
+                }
+                TakeMesh &o = meshes[(size_t)d.n_meshes + (size_t)i];
+                o = m;
+                o.positions = pos.data();
+                o.normals = m.normals ? nrm.data() : nullptr;
+                o.material_id = in.material_id >= 0 ? in.material_id : m.material_id;
+            }
+        };
+        const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads, d.n_instances));
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; t++) pool.emplace_back(work, d.n_instances * t / nt, d.n_instances * (t + 1) / nt);
+        for (auto &th : pool) th.join();
+        if (!err.empty()) return fail(TAKE_E_INVALID, err);
+        const size_t n0 = (size_t)d.n_shapes, n1 = n0 + (size_t)extra;
+        kind.resize(n1), ref.resize(n1), face.resize(n1), area_light.resize(n1);
+        if (n0) {
+            std::memcpy(kind.data(), d.shape_kind, n0 * 4), std::memcpy(ref.data(), d.shape_ref, n0 * 4);
+            std::memcpy(face.data(), d.shape_face, n0 * 4), std::memcpy(area_light.data(), d.shape_area_light, n0 * 4);
+        }
+        size_t at = n0;
+        for (int64_t i = 0; i < d.n_instances; i++) {
+            const int64_t nf = d.meshes[d.instances[i].mesh_id].n_faces;
+            for (int64_t k = 0; k < nf; k++, at++) kind[at] = 1, ref[at] = (int32_t)(d.n_meshes + i), face[at] = (int32_t)k, area_light[at] = -1;
+        }
+        d.meshes = meshes.data(), d.n_meshes = (int32_t)meshes.size();
+        d.shape_kind = kind.data(), d.shape_ref = ref.data(), d.shape_face = face.data(), d.shape_area_light = area_light.data();
+        d.n_shapes = (int64_t)n1;
+        d.n_instances = 0, d.instances = nullptr;
+        return TAKE_OK;
+    }
+};
+
 // Device-array meshes (TAKE_MESH_DEVICE_ARRAYS, take_hip_mesh_from_ply) in a scene description: the host side of the
 // build — index validation, the face / normal / uv tables, the SAH builder — reads host copies, staged here.
 struct StagedMeshes {
@@ -1459,6 +1552,7 @@ int take_hip_scene_create(const TakeSceneDesc *desc, const TakeBuildOpts *opts, 
     if (o.precision != TAKE_PRECISION_F32 && o.precision != TAKE_PRECISION_F64 && o.precision != TAKE_PRECISION_MIXED)
         return fail(TAKE_E_INVALID, "unknown precision");
     if (o.builder < TAKE_BUILDER_AUTO || o.builder > TAKE_BUILDER_HOST_SAH) return fail(TAKE_E_INVALID, "unknown builder");
+    if (o.instances != TAKE_INSTANCES_TWO_LEVEL && o.instances != TAKE_INSTANCES_FLATTEN) return fail(TAKE_E_INVALID, "unknown instance mode");
     TakeScene *ts = new (std::nothrow) TakeScene();
     if (!ts) return fail(TAKE_E_NOMEM, "out of host memory");
     ts->precision = o.precision;
@@ -1474,7 +1568,17 @@ int take_hip_scene_create(const TakeSceneDesc *desc, const TakeBuildOpts *opts, 
         // uv tables, the SAH builder below TAKE_AUTO_DEVICE_BUILD_SHAPES shapes — reads host copies; the device build
         // takes the positions where they are
         StagedMeshes staged;
+        FlattenedInstances flat;
         TakeSceneDesc local = *desc;
+        if (o.instances == TAKE_INSTANCES_FLATTEN) {
+            int threads = o.bvh_threads > 0 ? o.bvh_threads : (int)std::thread::hardware_concurrency();
+            const int rf = flat.expand(local, std::max(1, threads));
+            if (rf) {
+                delete ts;
+                return rf;
+            }
+        }
+        desc = &local;  // (from here on: the description as it will be built)
         const bool device_build = o.precision == TAKE_PRECISION_F32 && desc->n_shapes >= 8 && desc->n_instances == 0 &&
                                   (o.builder == TAKE_BUILDER_DEVICE_LBVH || (o.builder == TAKE_BUILDER_AUTO && desc->n_shapes >= TAKE_AUTO_DEVICE_BUILD_SHAPES));
         rc = staged.stage(local, !device_build);

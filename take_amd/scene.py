@@ -144,12 +144,21 @@ class SceneData:
         kinds, refs, faces, als = [out.shape_kind], [out.shape_ref], [out.shape_face], [out.shape_area_light]
         for mid, mat, x in zip(self.instance_mesh, self.instance_material, self.instance_xform):
             m = self.meshes[mid]
-            pos = m.positions @ x[:, :3].T + x[:, 3]
+            # (elementwise, left to right: the arithmetic of the library's own flattening, TAKE_INSTANCES_FLATTEN —
+            # the two expansions are bit-identical)
+            px, py, pz = m.positions[:, 0], m.positions[:, 1], m.positions[:, 2]
+            pos = np.stack([x[r, 0] * px + x[r, 1] * py + x[r, 2] * pz + x[r, 3] for r in range(3)], axis=1)
             nrm = None
             if m.normals is not None:
                 # rows: (L^-T n)^T = n^T L^-1; NOT re-normalised per vertex — interpolation commutes with the linear
                 # map only then (the interpolated normal is normalised at the hit, src/shape.cpp:105)
-                nrm = m.normals @ np.linalg.inv(x[:, :3])
+                (a00, a01, a02), (a10, a11, a12), (a20, a21, a22) = x[:, :3]
+                det = a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20)
+                inv = np.array([[(a11 * a22 - a12 * a21) / det, (a02 * a21 - a01 * a22) / det, (a01 * a12 - a02 * a11) / det],
+                                [(a12 * a20 - a10 * a22) / det, (a00 * a22 - a02 * a20) / det, (a02 * a10 - a00 * a12) / det],
+                                [(a10 * a21 - a11 * a20) / det, (a01 * a20 - a00 * a21) / det, (a00 * a11 - a01 * a10) / det]])
+                nx, ny, nz = m.normals[:, 0], m.normals[:, 1], m.normals[:, 2]
+                nrm = np.stack([nx * inv[0, c] + ny * inv[1, c] + nz * inv[2, c] for c in range(3)], axis=1)
             # (add_mesh, with the four shape arrays concatenated once at the end: 1000 placements of 10k triangles)
             nf = m.indices.shape[0]
             out.meshes.append(Mesh(np.ascontiguousarray(pos, np.float64), m.indices, m.material_id if mat < 0 else mat,

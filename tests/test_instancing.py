@@ -263,3 +263,48 @@ def test_host_braided_placements_equal_flattened(braid, monkeypatch):
     assert np.array_equal(a[:, 0], b[:, 0])
     hit = a[:, 0] >= 0
     assert hit.sum() > 2500 and np.abs(a[hit, 1] - b[hit, 1]).max() < 1e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,builder", [(D.TAKE_PRECISION_F32, D.TAKE_BUILDER_HOST_SAH), (D.TAKE_PRECISION_F32, D.TAKE_BUILDER_DEVICE_LBVH),
+                                               (D.TAKE_PRECISION_F64, D.TAKE_BUILDER_AUTO), (D.TAKE_PRECISION_MIXED, D.TAKE_BUILDER_AUTO)])
+def test_gpu_library_flattening_is_the_python_flattening(precision, builder):
+    """TakeBuildOpts.instances = TAKE_INSTANCES_FLATTEN: scene_create expands the placements itself (world-space
+    positions, n^T L^-1 normals, material override, shape ids in placement order).  Same arithmetic as
+    SceneData.flattened(), so the scene is the same scene: statistics, images and hit tables bit for bit."""
+    from helpers import random_rays, rays_to_abi
+    from take_amd import capi
+
+    for sd in (small(60, 300, 64), sheared_with_normals()):
+        a = capi.Scene(sd, precision=precision, builder=builder, flatten_instances=True)
+        b = capi.Scene(sd.flattened(), precision=precision, builder=builder)
+        c = capi.Scene(sd, precision=precision)  # two levels
+        try:
+            assert a.stats() == b.stats()
+            ia, ib = a.render(spp=4, max_depth=6, seed=5), b.render(spp=4, max_depth=6, seed=5)
+            assert np.array_equal(ia, ib) and ia.mean() > 0.01
+            rays = rays_to_abi(random_rays(4096, 3, tmin=1e-4), 0 if precision == D.TAKE_PRECISION_F32 else 1)
+            ha, hb, hc = a.trace_closest(rays), b.trace_closest(rays), c.trace_closest(rays)
+            for k in ("shape_id", "t", "u", "v"):
+                assert np.array_equal(ha[k], hb[k]), k
+            # the two-level scene numbers its shapes the same way (hits agree except where rounding moves an edge)
+            assert (ha["shape_id"] == hc["shape_id"]).mean() > 0.995 and (ha["shape_id"] >= 0).mean() > 0.05
+        finally:
+            a.close(), b.close(), c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_flattening_refuses_what_it_cannot_expand():
+    from take_amd import capi
+
+    sd = small(4, 50, 16)
+    sd.instance_mesh[2] = 99
+    with pytest.raises(capi.TakeError) as e:
+        capi.Scene(sd, flatten_instances=True)
+    assert e.value.code == D.TAKE_E_INVALID and "bad mesh index" in str(e.value)
+    sd = small(4, 50, 16)
+    sd.instance_xform[1] = np.zeros((3, 4))
+    sd.meshes[sd.instance_mesh[1]].normals = np.tile([0.0, 1.0, 0.0], (len(sd.meshes[sd.instance_mesh[1]].positions), 1))
+    with pytest.raises(capi.TakeError) as e:
+        capi.Scene(sd, flatten_instances=True)
+    assert "singular transform" in str(e.value)
