@@ -344,8 +344,12 @@ def main():
         acc, stats = main_leg["acc"], main_leg["stats"]
         mode = ("strong scaling: BASELINE configs[3], 4096x4096 x 1024 spp total, rows sharded over the ranks" if strong
                 else f"weak scaling: {args.spp} spp per GPU")
+        if args.instanced:
+            geometry = f"{args.instanced} instanced triangles (configs[4]'s shape)"
+        else:
+            geometry = "1M-tri soup" if args.tris == 1_000_000 else f"{args.tris}-tri soup"
         line = {
-            "metric": f"Msamples/s (camera paths/s: rays traced x spp / s), 1M-tri soup; {mode}",
+            "metric": f"Msamples/s (camera paths/s: rays traced x spp / s), {geometry}; {mode}",
             "value": main_leg["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_leg["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": {"mixed": "f64+f32"}.get(args.precision, args.precision), "data": "synthetic",
