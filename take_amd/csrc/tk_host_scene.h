@@ -40,7 +40,7 @@ template <class R> struct HostScene {
     std::vector<InstTrace<R>> inst_trace;  // two-level scenes (TakeInstance): one record per placement
     std::vector<InstShade<R>> inst_shade;
     int64_t n_blas = 0, blas_nodes = 0, blas_prims = 0;  // stats: prototype trees and their total size
-    EnvMap<R> env{-1, 0, 0, 0, 0, {R(0), R(0), R(0)}, nullptr, nullptr, nullptr, nullptr};  // pointers: view() / the uploader
+    EnvMap<R> env{-1, 0, 0, 1, 1, 0, 0, {R(0), R(0), R(0)}, nullptr, nullptr, nullptr, nullptr};  // pointers: view() / the uploader
     std::vector<R> env_marginal, env_conditional;
     std::vector<int32_t> env_guide_m, env_guide_c;
     R background[3];
@@ -682,7 +682,7 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
     if (!shape_err.empty()) return shape_err;
 
     // lights
-    hs.env = EnvMap<R>{-1, 0, 0, 0, 0, {R(0), R(0), R(0)}, nullptr, nullptr, nullptr, nullptr};
+    hs.env = EnvMap<R>{-1, 0, 0, 1, 1, 0, 0, {R(0), R(0), R(0)}, nullptr, nullptr, nullptr, nullptr};
     hs.env_marginal.clear(), hs.env_conditional.clear(), hs.env_guide_m.clear(), hs.env_guide_c.clear();
     hs.lights.resize(d.n_lights);
     for (int i = 0; i < d.n_lights; i++) {
@@ -718,12 +718,25 @@ std::string prepare_scene(const TakeSceneDesc &d, int max_leaf, int threads, Hos
                     out[k] = lo;
                 }
             };
-            hs.env_guide_m.resize(ENV_GUIDE_M + 1);
-            guide(hs.env_marginal.data(), im.height, ENV_GUIDE_M, hs.env_guide_m.data());
-            hs.env_guide_c.resize((size_t)im.height * (ENV_GUIDE_C + 1));
+            // one guide entry per ~quarter row / per column: the bisection that remains is 0-1 steps (round 3: with
+            // 256 / 64 entries it was 2-3 and ~5 dependent loads; shade kernel -4 % on the bench workload, same samples)
+            auto pow2_at_least = [](int v, int cap) {
+                int p = 1;
+                while (p < v && p < cap) p <<= 1;
+                return p;
+            };
+            int gm = pow2_at_least(4 * im.height, ENV_GUIDE_M_MAX), gc = pow2_at_least(im.width, ENV_GUIDE_C_MAX);
+            if (const char *e = std::getenv("TAKE_HIP_ENV_GUIDE")) {  // "<m>,<c>", powers of two
+                int a = 0, b = 0;
+                if (std::sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && !(a & (a - 1)) && !(b & (b - 1)) && a <= (1 << 16) && b <= (1 << 16)) gm = a, gc = b;
+            }
+            hs.env.n_guide_m = gm, hs.env.n_guide_c = gc;
+            hs.env_guide_m.resize(gm + 1);
+            guide(hs.env_marginal.data(), im.height, gm, hs.env_guide_m.data());
+            hs.env_guide_c.resize((size_t)im.height * (gc + 1));
             for (int y = 0; y < im.height; y++)
-                guide(hs.env_conditional.data() + (size_t)y * (im.width + 1), im.width, ENV_GUIDE_C,
-                      hs.env_guide_c.data() + (size_t)y * (ENV_GUIDE_C + 1));
+                guide(hs.env_conditional.data() + (size_t)y * (im.width + 1), im.width, gc,
+                      hs.env_guide_c.data() + (size_t)y * (gc + 1));
             continue;
         }
         if (l.kind != 1) return "light " + std::to_string(i) + ": unknown kind";

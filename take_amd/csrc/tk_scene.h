@@ -150,17 +150,18 @@ struct ImageInfo {
 template <class R> struct EnvMap {
     int32_t light;   // index of the env light in `lights`, -1 = none (then `background` is used)
     int32_t width, height;
-    int32_t pad;
+    int32_t n_guide_m;  // entries of the guide tables (powers of two: k = int(xi * n) is then exact), see below
+    int32_t n_guide_c, pad_;
     int64_t texel0;  // first texel of the image in `texels`
     R scale[3];
     const R *marginal;
     const R *conditional;
     // guide tables: entry k of a guide = the CDF interval that holds k / ENV_GUIDE_*; a look-up starts its bisection
-    // between two neighbouring entries (2-3 steps instead of 10-11), with the same result
-    const int32_t *guide_m;  // ENV_GUIDE_M + 1 entries
-    const int32_t *guide_c;  // height rows of ENV_GUIDE_C + 1 entries
+    // between two neighbouring entries (0-1 steps instead of 10-11), with the same result
+    const int32_t *guide_m;  // n_guide_m + 1 entries
+    const int32_t *guide_c;  // height rows of n_guide_c + 1 entries
 };
-constexpr int ENV_GUIDE_M = 256, ENV_GUIDE_C = 64;
+constexpr int ENV_GUIDE_M_MAX = 1 << 16, ENV_GUIDE_C_MAX = 1 << 13;  // (sizes: tk_host_scene.h; TAKE_HIP_ENV_GUIDE=<m>,<c> overrides them for A/B runs)
 template <class R> struct LightRec {
     int32_t kind;      // 0 point, 1 diffuse area, 2 environment map (see EnvMap)
     int32_t shape_id;  // -1 for point lights

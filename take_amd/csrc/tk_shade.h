@@ -174,9 +174,9 @@ template <class R> TK_HD int cdf_find_guided(const R *cdf, int n, const int32_t 
 template <class R, class G> TK_HD EnvSample<R> env_sample(const DeviceScene<R> &sc, G &rng) {
     const R u1 = random_real<R>(rng);
     const R u2 = random_real<R>(rng);
-    const int y = cdf_find_guided(sc.env.marginal, sc.env.height, sc.env.guide_m, ENV_GUIDE_M, u1);
+    const int y = cdf_find_guided(sc.env.marginal, sc.env.height, sc.env.guide_m, sc.env.n_guide_m, u1);
     const R *row = sc.env.conditional + (int64_t)y * (sc.env.width + 1);
-    const int x = cdf_find_guided(row, sc.env.width, sc.env.guide_c + (int64_t)y * (ENV_GUIDE_C + 1), ENV_GUIDE_C, u2);
+    const int x = cdf_find_guided(row, sc.env.width, sc.env.guide_c + (int64_t)y * (sc.env.n_guide_c + 1), sc.env.n_guide_c, u2);
     const R m0 = sc.env.marginal[y], m1 = sc.env.marginal[y + 1], c0 = row[x], c1 = row[x + 1];
     const R dv = m1 > m0 ? (u1 - m0) / (m1 - m0) : R(0.5), du = c1 > c0 ? (u2 - c0) / (c1 - c0) : R(0.5);
     const R theta = (R(y) + dv) / R(sc.env.height) * Const<R>::PI;
