@@ -829,14 +829,15 @@ template <class R> struct ShadeArgs {
     unsigned long long *counters;
     int grid;
     hipStream_t stream;
+    float *to_f32;  // mixed precision, last exact round: the f32 records the continuing paths are converted into (else null)
 };
 template <class R, int TAG> void launch_shade_tag(const ShadeArgs<R> &a) {
     if (a.rp.integrator != 0)
         hipLaunchKernelGGL((k_shade<R, TAG, true>), dim3(a.grid), dim3(BLOCK), 0, a.stream, a.dev, a.rp, a.st, a.queue, a.n_cur,
-                           a.tag_count, a.next_queue, a.n_next, a.shadow_queue, a.n_shadow, a.k, a.counters);
+                           a.tag_count, a.next_queue, a.n_next, a.shadow_queue, a.n_shadow, a.k, a.counters, a.to_f32);
     else
         hipLaunchKernelGGL((k_shade<R, TAG, false>), dim3(a.grid), dim3(BLOCK), 0, a.stream, a.dev, a.rp, a.st, a.queue, a.n_cur,
-                           a.tag_count, a.next_queue, a.n_next, a.shadow_queue, a.n_shadow, a.k, a.counters);
+                           a.tag_count, a.next_queue, a.n_next, a.shadow_queue, a.n_shadow, a.k, a.counters, a.to_f32);
 }
 template <class R> void launch_shade(int tag, const ShadeArgs<R> &a) {
     switch (tag) {
@@ -887,9 +888,18 @@ struct RoundWs {
 };
 // One round k of a batch on the records of precision RR: closest hits of the extend queue, material sort, shade,
 // shadow rays.  (Everything is enqueued; nothing waits.)
+// Round 0 of the default integrator on the default node format: no generate pass (CameraIo).  The counting instances,
+// the other integrators (their shade rounds read the initial flag word) and the other node formats keep k_generate.
+// TAKE_HIP_CAMERA_FUSED=0 turns it off (A/B runs).
+template <class RR> bool camera_fused(const SceneT<RR> &sc, const RenderParams<RR> &rp, bool counting) {
+    static const bool enabled = !(std::getenv("TAKE_HIP_CAMERA_FUSED") && std::atoi(std::getenv("TAKE_HIP_CAMERA_FUSED")) == 0);
+    return enabled && TQ_GROUP == 1 && !counting && rp.integrator == 0 && sc.dev.qnodes != nullptr && sc.dev.qnodes8 == nullptr;
+}
+
 template <class RR>
 void launch_round(TakeScene *ts, SceneT<RR> &sc, const RoundWs &ws, PathState<RR> st, const RenderParams<RR> &rp, int k, int64_t n_bound,
-                  Timer &tm, bool counting, bool sort_materials, hipStream_t stream, int64_t dump, int64_t slots, bool tail = false) {
+                  Timer &tm, bool counting, bool sort_materials, hipStream_t stream, int64_t dump, int64_t slots, bool tail = false,
+                  float *to_f32 = nullptr) {
     int32_t *q = ws.q;
     int32_t *tag_count = q + Q_NUM_WORDS;
     const int cur = k & 1, next = cur ^ 1;
@@ -900,8 +910,21 @@ void launch_round(TakeScene *ts, SceneT<RR> &sc, const RoundWs &ws, PathState<RR
     const dim3 tgrid((unsigned)std::max<int64_t>(1, std::min<int64_t>(sc.trace_grid, (n_bound + 127) / 128)));
     hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, stream, q, next);
     tm.begin(tail ? TK_CLOSEST_TAIL : TK_CLOSEST);
-    launch_trace<RR>(sc.group, false, counting, tgrid, stream, sc.dev, io_ext, n_cur, 0, q + Q_HEAD_CLOSEST, ws.counters,
-                     tail ? (int)C_RAYS_CLOSEST_TAIL : (int)C_RAYS_CLOSEST, spill);
+    if (k == 0 && camera_fused<RR>(sc, rp, counting)) {
+        // (the camera rays are made by the launch that traces them: CameraIo, tk_kernels.h)
+        CameraIo<RR> io_cam;
+        static_cast<PathIo<RR> &>(io_cam) = io_ext;
+        io_cam.cam = sc.dev.cam, io_cam.rp = rp;
+        if (sc.dev.inst_trace)
+            hipLaunchKernelGGL((k_trace_group<RR, TQ_GROUP, false, false, CameraIo<RR>, true, true, 4>), tgrid, dim3(TQ_BLOCK), 0, stream, sc.dev,
+                               io_cam, n_cur, 0, q + Q_HEAD_CLOSEST, ws.counters, (int)C_RAYS_CLOSEST, spill);
+        else
+            hipLaunchKernelGGL((k_trace_group<RR, TQ_GROUP, false, false, CameraIo<RR>, true, false, 4>), tgrid, dim3(TQ_BLOCK), 0, stream, sc.dev,
+                               io_cam, n_cur, 0, q + Q_HEAD_CLOSEST, ws.counters, (int)C_RAYS_CLOSEST, spill);
+    } else {
+        launch_trace<RR>(sc.group, false, counting, tgrid, stream, sc.dev, io_ext, n_cur, 0, q + Q_HEAD_CLOSEST, ws.counters,
+                         tail ? (int)C_RAYS_CLOSEST_TAIL : (int)C_RAYS_CLOSEST, spill);
+    }
     tm.end();
     if (dump >= 0 && dump < slots) dump_slot(st, dump, "after trace_closest", k, stream);
     const int32_t *shade_in = ws.queue[cur];
@@ -923,7 +946,7 @@ void launch_round(TakeScene *ts, SceneT<RR> &sc, const RoundWs &ws, PathState<RR
     {
         const int shade_grid = (int)((n_bound + BLOCK - 1) / BLOCK);
         ShadeArgs<RR> sa{sc.dev, rp, st, shade_in, n_cur, sort_materials ? tag_count : nullptr, ws.queue[next],
-                         n_next, ws.shadow_queue, q + Q_N_SHADOW, k, ws.counters, shade_grid, stream};
+                         n_next, ws.shadow_queue, q + Q_N_SHADOW, k, ws.counters, shade_grid, stream, to_f32};
         if (sort_materials) {
             // one specialised launch per material tag present in the scene + the miss segment
             for (int t = 0; t < TAKE_MAT_COUNT; t++)
@@ -1072,9 +1095,9 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
         rp.s0 = (int32_t)first_sample + s0;
         rp.spb = nb;
         rp32.s0 = rp.s0, rp32.spb = nb;
-        if (mixed) HIP_TRY(hipMemsetAsync(ts->f.state_r.p, 0, sizeof(float) * (size_t)PATH_REC * (size_t)n, stream));
         tm.begin(TK_OTHER);
-        hipLaunchKernelGGL((k_generate<R>), dim3(wide_grid), dim3(BLOCK), 0, stream, sc.dev, rp, st, sc.queue[0].p, n);
+        if (camera_fused<R>(sc, rp, counting)) hipLaunchKernelGGL(k_iota, dim3(wide_grid), dim3(BLOCK), 0, stream, sc.queue[0].p, n);
+        else hipLaunchKernelGGL((k_generate<R>), dim3(wide_grid), dim3(BLOCK), 0, stream, sc.dev, rp, st, sc.queue[0].p, n);
         hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, stream, q, (int)Q_N_EXT0, (int32_t)n);
         tm.end();
         const int rounds = o.max_depth + 2;
@@ -1083,15 +1106,17 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
             const int next = (k & 1) ^ 1;
             int32_t *n_next = q + (next ? Q_N_EXT1 : Q_N_EXT0);
             if constexpr (sizeof(R) == 8) {
-                if (mixed && k == exact_rounds) {
+                if (mixed && k == exact_rounds && !TK_SHADE_RECORD) {
                     // mixed precision: the paths still alive continue on f32 records (and the f32 scene) from here on
+                    // (with TK_SHADE_RECORD the last exact shade round has written them already: k_shade, to_f32)
                     tm.begin(TK_OTHER);
                     hipLaunchKernelGGL(k_convert_state, dim3(wide_grid), dim3(BLOCK), 0, stream, st, st32, ws.queue[k & 1],
                                        q + ((k & 1) ? Q_N_EXT1 : Q_N_EXT0));
                     tm.end();
                 }
                 if (mixed && k >= exact_rounds) launch_round<float>(ts, ts->f, ws, st32, rp32, k, n_bound, tm, counting, sort_materials, stream, -1, slots, true);
-                else launch_round<R>(ts, sc, ws, st, rp, k, n_bound, tm, counting, sort_materials, stream, dump, slots);
+                else launch_round<R>(ts, sc, ws, st, rp, k, n_bound, tm, counting, sort_materials, stream, dump, slots, false,
+                                     (mixed && TK_SHADE_RECORD && k == exact_rounds - 1) ? st32.r : nullptr);
             } else {
                 launch_round<R>(ts, sc, ws, st, rp, k, n_bound, tm, counting, sort_materials, stream, dump, slots);
             }

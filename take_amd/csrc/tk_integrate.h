@@ -52,17 +52,26 @@ template <class R> TK_HD Rng path_rng(const RenderParams<R> &rp, int64_t slot, u
 
 // Camera ray of src/render.cpp:69-75.  The two jitters are drawn y first (the g++ evaluation order the golden
 // vectors pin).
-template <class R>
-TK_HD void generate_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, const PathState<R> &st, int64_t slot) {
+constexpr uint32_t CAMERA_DRAWS = 2;  // random numbers a camera ray consumes: a path's stream continues at this counter
+template <class R> TK_HD Vec3<R> camera_dir(const CameraRec<R> &c, const RenderParams<R> &rp, int64_t slot) {
     const int p = (int)(slot % rp.npix);
     const int lr = p / rp.width, x = p % rp.width;
     const int y = local_row_to_y(rp, lr);
     Rng rng = path_rng(rp, slot, 0);
     const R ry = random_real<R>(rng);
     const R rx = random_real<R>(rng);
+    return normalize(ld3(c.u) * ((R(x) + rx) / R(c.width) - R(0.5)) * c.viewport_width +
+                     ld3(c.v) * ((R(y) + ry) / R(c.height) - R(0.5)) * c.viewport_height - ld3(c.w));
+}
+// The whole initial record of a path.  (The render loop of the default integrator does not run this: its first
+// closest-hit launch makes the camera rays itself — CameraIo, tk_kernels.h — and round 0 of shade_path starts from
+// throughput 1, radiance 0 and counter CAMERA_DRAWS whatever the record holds; this function states what that equals.)
+template <class R>
+TK_HD void generate_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, const PathState<R> &st, int64_t slot) {
     const CameraRec<R> &c = sc.cam;
-    Vec3<R> d = normalize(ld3(c.u) * ((R(x) + rx) / R(c.width) - R(0.5)) * c.viewport_width +
-                          ld3(c.v) * ((R(y) + ry) / R(c.height) - R(0.5)) * c.viewport_height - ld3(c.w));
+    const Vec3<R> d = camera_dir(c, rp, slot);
+    Rng rng = path_rng(rp, slot, 0);
+    rng.ctr = CAMERA_DRAWS;
     st.R_(S_OX, slot) = c.lookfrom[0];
     st.R_(S_OY, slot) = c.lookfrom[1];
     st.R_(S_OZ, slot) = c.lookfrom[2];
@@ -78,6 +87,7 @@ TK_HD void generate_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, co
     st.I_(S_CTR, slot) = (int32_t)rng.ctr;
     st.I_(S_FLAGS, slot) = 0;
     st.I_(S_OCC, slot) = -1;
+    st.I_(S_CONV, slot) = 0;
 }
 
 constexpr uint32_t REQ_EXTEND = 1, REQ_SHADOW = 2;
@@ -96,6 +106,11 @@ TK_HD uint32_t shade_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, c
     const Vec3<R> rd{st.R_(S_DX, slot), st.R_(S_DY, slot), st.R_(S_DZ, slot)};
     Vec3<R> thr{st.R_(S_TX, slot), st.R_(S_TY, slot), st.R_(S_TZ, slot)};
     Vec3<R> rad{st.R_(S_LX, slot), st.R_(S_LY, slot), st.R_(S_LZ, slot)};
+    if (k == 0) {  // a path starts here: what generate_path writes, without needing it written (see there)
+        thr = Vec3<R>{R(1), R(1), R(1)};
+        rad = Vec3<R>{R(0), R(0), R(0)};
+        if (sizeof(R) == 8) st.I_(S_CONV, slot) = 0;  // (f64 records only: in the f32 shade kernel the store cost two registers and with them the fifth wave)
+    }
     const Vec3<R> bg = ld3(sc.background);
     const R nlights = R(sc.n_lights);
     const bool miss = (TAG == TAG_MISS) || hit_prim < 0;
@@ -157,7 +172,7 @@ TK_HD uint32_t shade_path(const DeviceScene<R> &sc, const RenderParams<R> &rp, c
     uint32_t req = 0;
     if (TAG != TAG_MISS && alive && k <= rp.max_depth) {
         // first half of loop iteration k: src/integrator/path_tracing.h:22-81
-        Rng rng = path_rng(rp, slot, (uint32_t)st.I_(S_CTR, slot));
+        Rng rng = path_rng(rp, slot, k == 0 ? CAMERA_DRAWS : (uint32_t)st.I_(S_CTR, slot));
         const Vec3<R> dir_in = -rd;
         const MaterialRec<R> &m = sc.materials[v.material];
         constexpr int MT = (TAG >= 0 && TAG < TAG_MISS) ? TAG : -1;

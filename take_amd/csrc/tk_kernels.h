@@ -49,6 +49,29 @@ k_generate(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, int32_t *queu
     }
 }
 
+// Round 0 without a generate pass: the closest-hit launch of the camera rays makes each ray itself (two random numbers
+// and a normalise) instead of reading it from a record that a kernel before it wrote — k_generate moved 100 B per path
+// through HBM for nothing (35 ms of a 6.7 s mixed step in f64, 18 ms in f32).  The ray goes into the path record with
+// the hit (same cache line), where the shade round and — in two-level scenes — reload() find it; the work list is the
+// identity, so no queue is read.  Everything else of the initial record (throughput 1, radiance 0, stream counter) is
+// implied by k == 0 in shade_path.
+template <class R> struct CameraIo : PathIo<R> {
+    CameraRec<R> cam;
+    RenderParams<R> rp;
+    template <bool SHADOW> __device__ __forceinline__ void load(int32_t i, RayT<R> &ray, int32_t &tag) const {
+        const int64_t slot = i;
+        tag = i;
+        const Vec3<R> d = camera_dir(cam, rp, slot);
+        const PathState<R> &st = this->st;
+        st.R_(S_OX, slot) = cam.lookfrom[0], st.R_(S_OY, slot) = cam.lookfrom[1], st.R_(S_OZ, slot) = cam.lookfrom[2];
+        st.R_(S_DX, slot) = d.x, st.R_(S_DY, slot) = d.y, st.R_(S_DZ, slot) = d.z;
+        ray = make_ray(cam.lookfrom[0], cam.lookfrom[1], cam.lookfrom[2], d.x, d.y, d.z, this->eps, Const<R>::inf());
+    }
+};
+__global__ void __launch_bounds__(BLOCK) k_iota(int32_t *queue, int64_t n) {
+    for (int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x; s < n; s += (int64_t)gridDim.x * BLOCK) queue[s] = (int32_t)s;
+}
+
 // One integrator round.  Requests are compacted into the next extend queue and the shadow queue with one
 // atomic per wave and queue (ballot + mbcnt prefix).
 // TAG: the kernel is instantiated per material tag (+ TAG_MISS).  With a sorted queue (`tag_count` != null) an
@@ -79,7 +102,7 @@ template <class R, int TAG, bool ALT = false>
 __global__ void __launch_bounds__(BLOCK, (sizeof(R) == 4 ? TK_SHADE_WAVES_F32 : TK_SHADE_WAVES_F64) > 0 ? (sizeof(R) == 4 ? TK_SHADE_WAVES_F32 : TK_SHADE_WAVES_F64) : 1)
 k_shade(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, const int32_t *__restrict__ queue,
         const int32_t *__restrict__ n_ptr, const int32_t *__restrict__ tag_count, int32_t *next_queue,
-        int32_t *n_next, int32_t *shadow_queue, int32_t *n_shadow, int k, unsigned long long *counters) {
+        int32_t *n_next, int32_t *shadow_queue, int32_t *n_shadow, int k, unsigned long long *counters, float *to_f32) {
     int32_t begin = 0, n = *n_ptr;
     if (tag_count) {
         for (int t = 0; t < TAG; t++) begin += tag_count[t];
@@ -152,6 +175,25 @@ k_shade(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, const int32_t *_
                 : "memory");
             req = ALT ? shade_path_alt<R, TAG, RecordView<R>>(sc, rp, rv, (int64_t)slot, k)
                       : shade_path<R, TAG, RecordView<R>>(sc, rp, rv, (int64_t)slot, k);
+            // mixed precision, last exact round (to_f32 = the f32 records): a path that goes on does so in the f32
+            // record of its slot — ray, throughput, radiance so far, pending BSDF sample, stream counter, flags — written
+            // here, from the registers that hold them, instead of by a pass of its own over both record sets.  The
+            // radiance moves with the path: the f64 record keeps only what this round's shadow ray still adds.
+            if (to_f32 != nullptr && (req & REQ_EXTEND)) {
+                RecordView<float> fv;
+#pragma unroll
+                for (int c = 0; c < PATH_REC / 4; c++) fv.q[c] = make_uint4(0, 0, 0, 0);
+                constexpr int WORDS[] = {S_OX, S_OY, S_OZ, S_DX, S_DY, S_DZ, S_PDF, S_TX, S_TY, S_TZ, S_LX, S_LY, S_LZ, S_FX, S_FY, S_FZ};
+#pragma unroll
+                for (int w = 0; w < 16; w++) fv.w[WORDS[w]] = (float)rv.w[WORDS[w]];
+                fv.I_(S_CTR, 0) = rv.I_(S_CTR, 0);
+                fv.I_(S_FLAGS, 0) = rv.I_(S_FLAGS, 0);
+                rv.w[S_LX] = 0.0, rv.w[S_LY] = 0.0, rv.w[S_LZ] = 0.0;
+                rv.I_(S_CONV, 0) = 1;
+                uint4 *out32 = (uint4 *)(to_f32 + (int64_t)slot * PATH_REC);
+#pragma unroll
+                for (int c = 0; c < PATH_REC / 4; c++) out32[c] = fv.q[c];
+            }
             uint4 *out = (uint4 *)(st.r + (int64_t)slot * PATH_REC);
 #pragma unroll
             for (int c = 0; c < 16; c++) out[c] = rv.q[c];
@@ -309,7 +351,9 @@ k_accumulate(PathState<R> st, R *accum, int32_t npix, int32_t spb) {
 // Mixed precision (TAKE_PRECISION_MIXED): the paths of `queue` (alive after the exact rounds) continue on f32 records
 // of the same slots: ray, throughput, radiance so far, pending BSDF sample, random-stream counter, flags.  The radiance
 // moves with the path (the f64 record's is cleared), so that a sample's value is the sum of the two records' radiance
-// whichever round its path ended in (k_accumulate_mixed; the f32 records' radiance words are zeroed per batch).
+// whichever round its path ended in (k_accumulate_mixed; S_CONV in the f64 record says whether the f32 record counts).
+// The render loop does this inside the last exact shade round (k_shade, to_f32); this kernel is the stand-alone form
+// for builds without the register copy of the record (TK_SHADE_RECORD = 0).
 __global__ void __launch_bounds__(BLOCK)
 k_convert_state(PathState<double> a, PathState<float> b, const int32_t *__restrict__ queue, const int32_t *__restrict__ n_ptr) {
     const int32_t n = *n_ptr;
@@ -321,6 +365,7 @@ k_convert_state(PathState<double> a, PathState<float> b, const int32_t *__restri
         b.I_(S_CTR, s) = a.I_(S_CTR, s);
         b.I_(S_FLAGS, s) = a.I_(S_FLAGS, s);
         a.R_(S_LX, s) = 0.0, a.R_(S_LY, s) = 0.0, a.R_(S_LZ, s) = 0.0;
+        a.I_(S_CONV, s) = 1;
     }
 }
 __global__ void __launch_bounds__(BLOCK)
@@ -329,9 +374,13 @@ k_accumulate_mixed(PathState<double> a, PathState<float> b, double *accum, int32
         double r = accum[3 * (int64_t)p], g = accum[3 * (int64_t)p + 1], bl = accum[3 * (int64_t)p + 2];
         for (int s = 0; s < spb; s++) {
             const int64_t slot = (int64_t)s * npix + p;
-            r = r + (a.R_(S_LX, slot) + (double)b.R_(S_LX, slot));
-            g = g + (a.R_(S_LY, slot) + (double)b.R_(S_LY, slot));
-            bl = bl + (a.R_(S_LZ, slot) + (double)b.R_(S_LZ, slot));
+            // (S_CONV: the f32 record of a slot holds this batch's path only if the path was converted)
+            // (loaded whatever the flag says, then selected: a load that waits for the flag halves the loads in flight)
+            const bool conv = a.I_(S_CONV, slot) != 0;
+            const float bx = b.R_(S_LX, slot), by = b.R_(S_LY, slot), bz = b.R_(S_LZ, slot);
+            r = r + (a.R_(S_LX, slot) + (conv ? (double)bx : 0.0));
+            g = g + (a.R_(S_LY, slot) + (conv ? (double)by : 0.0));
+            bl = bl + (a.R_(S_LZ, slot) + (conv ? (double)bz : 0.0));
         }
         accum[3 * (int64_t)p] = r;
         accum[3 * (int64_t)p + 1] = g;

@@ -246,10 +246,12 @@ enum StateR {
     S_CX, S_CY, S_CZ,          // throughput * C1: added to radiance if the shadow ray is unoccluded
     S_NUM_R = 29
 };
-enum StateI { S_HIT = 9, S_CTR = 10, S_FLAGS = 11, S_INST = 29, S_OCC = 30, S_NUM_I = 5 };  // integer words of the same record
+enum StateI { S_HIT = 9, S_CTR = 10, S_FLAGS = 11, S_INST = 29, S_OCC = 30, S_CONV = 31, S_NUM_I = 6 };  // integer words of the same record
 // S_HIT: index of the hit primitive (leaf order), -1 = the extend ray missed
 // S_INST: instance the hit primitive was reached through (two-level scenes only; -1 = none)
 // S_OCC: counting mode only (an instrument): the primitive that occluded this slot's previous shadow ray
+// S_CONV: mixed precision, f64 records only: 1 = this path went on in the f32 record of its slot (its radiance is the
+//         sum of the two records'); cleared by round 0 of every batch (same cache line as the radiance words)
 constexpr int PATH_REC = 32;
 constexpr int32_t FLAG_SPECULAR = 1;
 
