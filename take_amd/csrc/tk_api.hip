@@ -373,6 +373,7 @@ struct FlattenedInstances {
         std::string err;
         std::mutex mu;
         auto work = [&](int64_t lo, int64_t hi) {
+            try {
             for (int64_t i = lo; i < hi; i++) {
                 const TakeInstance &in = d.instances[i];
                 const TakeMesh &m = d.meshes[in.mesh_id];
@@ -409,6 +410,10 @@ struct FlattenedInstances {
                 o.positions = pos.data();
                 o.normals = m.normals ? nrm.data() : nullptr;
                 o.material_id = in.material_id >= 0 ? in.material_id : m.material_id;
+            }
+            } catch (const std::exception &) {  // (an exception must not leave a worker thread)
+                std::lock_guard<std::mutex> lock(mu);
+                err = "out of host memory while flattening the instances";
             }
         };
         const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads, d.n_instances));

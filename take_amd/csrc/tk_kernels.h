@@ -93,13 +93,19 @@ template <class R> struct RecordView {
     __device__ __forceinline__ int32_t &I_(int c, int64_t) const { return *reinterpret_cast<int32_t *>(&w[c]); }
 };
 #ifndef TK_SHADE_WAVES_F32
-#define TK_SHADE_WAVES_F32 0  // register cap of the shade kernels in waves per SIMD (0: none): tuning knob, DESIGN.md §7
+#define TK_SHADE_WAVES_F32 5  // register cap of the shade kernels in waves per SIMD (0: none).  The f32 Diffuse instance sits at 96 VGPRs = the last count that gives five waves; 97 is four, and the fifth wave is worth 4 % of its time: the cap keeps an innocent edit from costing it
 #endif
 #ifndef TK_SHADE_WAVES_F64
 #define TK_SHADE_WAVES_F64 0
 #endif
+// (the f32 cap applies to the Diffuse instance of the default integrator — the one the headline workload runs; the
+// other tags would pay for a cap with scratch)
+template <class R, int TAG, bool ALT> constexpr int shade_waves() {
+    const int w = sizeof(R) == 4 ? ((TAG == 0 && !ALT) ? TK_SHADE_WAVES_F32 : 0) : TK_SHADE_WAVES_F64;
+    return w > 0 ? w : 1;
+}
 template <class R, int TAG, bool ALT = false>
-__global__ void __launch_bounds__(BLOCK, (sizeof(R) == 4 ? TK_SHADE_WAVES_F32 : TK_SHADE_WAVES_F64) > 0 ? (sizeof(R) == 4 ? TK_SHADE_WAVES_F32 : TK_SHADE_WAVES_F64) : 1)
+__global__ void __launch_bounds__(BLOCK, (shade_waves<R, TAG, ALT>()))
 k_shade(DeviceScene<R> sc, RenderParams<R> rp, PathState<R> st, const int32_t *__restrict__ queue,
         const int32_t *__restrict__ n_ptr, const int32_t *__restrict__ tag_count, int32_t *next_queue,
         int32_t *n_next, int32_t *shadow_queue, int32_t *n_shadow, int k, unsigned long long *counters, float *to_f32) {
