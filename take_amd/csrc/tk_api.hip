@@ -1041,6 +1041,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
     PathState<R> st{sc.state_r.p, sc.capacity};
     RenderParams<R> rp{};
     rp.width = W, rp.height = H, rp.n_local_rows = n_rows, rp.npix = (int32_t)npix;
+    rp.inv_npix = 1.0 / (double)npix, rp.inv_width = 1.0 / (double)W;
     rp.strip_first = first, rp.strip_stride = stride;
     rp.spp = o.spp, rp.max_depth = o.max_depth, rp.seed = o.seed, rp.integrator = o.integrator;
     rp.ray_eps = o.ray_epsilon > 0 ? R(o.ray_epsilon) : (sizeof(R) == 8 ? R(1e-7) : R(1e-4));
@@ -1079,6 +1080,7 @@ template <class R> int render_impl(TakeScene *ts, const TakeRenderOpts &o, void 
             if (o.integrator != 0) return fail(TAKE_E_INVALID, "mixed precision renders the reference's path_tracing (integrator 0) only");
             st32 = PathState<float>{ts->f.state_r.p, slots};
             rp32.width = rp.width, rp32.height = rp.height, rp32.n_local_rows = rp.n_local_rows, rp32.npix = rp.npix;
+            rp32.inv_npix = rp.inv_npix, rp32.inv_width = rp.inv_width;
             rp32.strip_first = rp.strip_first, rp32.strip_stride = rp.strip_stride, rp32.spp = rp.spp, rp32.max_depth = rp.max_depth;
             rp32.integrator = rp.integrator, rp32.seed = rp.seed;
             rp32.ray_eps = o.ray_epsilon > 0 ? (float)o.ray_epsilon : 1e-4f;

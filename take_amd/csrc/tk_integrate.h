@@ -27,7 +27,30 @@ template <class R> struct RenderParams {
     int32_t integrator;     // TakeRenderOpts.integrator: 0 path_tracing, 1 raw, 2 one-sample MIS, 3 one-sample MIS by power
     uint64_t seed;
     R ray_eps;
+    double inv_npix, inv_width;  // 1.0 / npix, 1.0 / width for slot_pixel (0: not set — plain division)
 };
+
+// n / d and n % d for n, d < 2^31 with the reciprocal of the (launch-invariant) divisor: the product is within 2^-20
+// of the true quotient, so its floor is off by at most one and one correction makes it exact.  Every path of every
+// shade round starts with two such divisions (slot -> sample, pixel -> row, column); as integer divisions they were
+// ~130 of the shade kernel's instructions per path.
+TK_HD void divmod_u31(uint32_t n, uint32_t d, double inv_d, uint32_t &q, uint32_t &r) {
+    if (inv_d == 0.0) {
+        q = n / d, r = n % d;
+        return;
+    }
+    q = (uint32_t)((double)n * inv_d);
+    r = n - q * d;
+    if ((int32_t)r < 0) q -= 1, r += d;
+    else if (r >= d) q += 1, r -= d;
+}
+// path slot -> (sample of the batch, local row, column)
+template <class R> TK_HD void slot_pixel(const RenderParams<R> &rp, int64_t slot, int &sl, int &lr, int &x) {
+    uint32_t q, p, row, col;
+    divmod_u31((uint32_t)slot, (uint32_t)rp.npix, rp.inv_npix, q, p);
+    divmod_u31(p, (uint32_t)rp.width, rp.inv_width, row, col);
+    sl = (int)q, lr = (int)row, x = (int)col;
+}
 
 // Multi-GPU unit: a strip of STRIP_ROWS image rows, dealt round-robin to the ranks.  (The reference's own unit is
 // a 16-row tile row, src/render.cpp:52; 4-row strips balance better: 1080 rows over 8 ranks = 136 vs 132 rows per
@@ -40,9 +63,8 @@ template <class R> TK_HD int local_row_to_y(const RenderParams<R> &rp, int lr) {
 }
 
 template <class R> TK_HD Rng path_rng(const RenderParams<R> &rp, int64_t slot, uint32_t ctr) {
-    const int p = (int)(slot % rp.npix);
-    const int sl = (int)(slot / rp.npix);
-    const int lr = p / rp.width, x = p % rp.width;
+    int sl, lr, x;
+    slot_pixel(rp, slot, sl, lr, x);
     const int y = local_row_to_y(rp, lr);
     Rng r;
     r.key = rng_key(rp.seed, (uint64_t)y * (uint64_t)rp.width + (uint64_t)x, (uint64_t)(rp.s0 + sl));
@@ -54,8 +76,8 @@ template <class R> TK_HD Rng path_rng(const RenderParams<R> &rp, int64_t slot, u
 // vectors pin).
 constexpr uint32_t CAMERA_DRAWS = 2;  // random numbers a camera ray consumes: a path's stream continues at this counter
 template <class R> TK_HD Vec3<R> camera_dir(const CameraRec<R> &c, const RenderParams<R> &rp, int64_t slot) {
-    const int p = (int)(slot % rp.npix);
-    const int lr = p / rp.width, x = p % rp.width;
+    int sl, lr, x;
+    slot_pixel(rp, slot, sl, lr, x);
     const int y = local_row_to_y(rp, lr);
     Rng rng = path_rng(rp, slot, 0);
     const R ry = random_real<R>(rng);

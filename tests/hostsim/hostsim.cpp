@@ -57,6 +57,7 @@ template <class R> int render_t(const TakeSceneDesc &desc, const TakeRenderOpts 
     const int64_t npix = (int64_t)n_rows * W;
     RenderParams<R> rp{};
     rp.width = W, rp.height = H, rp.n_local_rows = n_rows, rp.npix = (int32_t)npix;
+    rp.inv_npix = 1.0 / (double)npix, rp.inv_width = 1.0 / (double)W;
     rp.strip_first = o.strip_first, rp.strip_stride = stride;
     rp.spp = o.spp, rp.max_depth = o.max_depth, rp.seed = o.seed, rp.integrator = o.integrator;
     rp.ray_eps = o.ray_epsilon > 0 ? R(o.ray_epsilon) : (sizeof(R) == 8 ? R(1e-7) : R(1e-4));
@@ -202,6 +203,39 @@ int hostsim_render(const TakeSceneDesc *desc, int precision, const TakeRenderOpt
     return precision == TAKE_PRECISION_F64 ? render_t<double>(*desc, *opts, out, stats)
                                            : render_t<float>(*desc, *opts, out, stats);
 }
+// divmod_u31 (tk_integrate.h: the slot -> sample / pixel divisions of every shade round, by reciprocal) against the
+// integer division, on divisors and dividends around every power of two, the extremes and `n_random` random pairs;
+// returns the number of disagreements
+int64_t hostsim_check_divmod(int64_t n_random, uint64_t seed) {
+    int64_t bad = 0;
+    auto check = [&](uint32_t n, uint32_t d) {
+        if (d == 0 || n >= (1u << 31) || d >= (1u << 31)) return;
+        uint32_t q, r;
+        tk::divmod_u31(n, d, 1.0 / (double)d, q, r);
+        bad += (q != n / d) || (r != n % d);
+    };
+    std::vector<uint32_t> edge;
+    for (int b = 0; b < 31; b++)
+        for (int64_t k = -2; k <= 2; k++) {
+            const int64_t v = ((int64_t)1 << b) + k;
+            if (v > 0 && v < ((int64_t)1 << 31)) edge.push_back((uint32_t)v);
+        }
+    edge.push_back((1u << 31) - 1), edge.push_back(1920 * 1080), edge.push_back(1920), edge.push_back(4096 * 4096), edge.push_back(3);
+    for (uint32_t d : edge)
+        for (uint32_t n : edge) {
+            check(n, d);
+            check((uint32_t)std::min<uint64_t>((uint64_t)n * d, (1ull << 31) - 1), d);      // exact multiples
+            check((uint32_t)std::min<uint64_t>((uint64_t)n * d + d - 1, (1ull << 31) - 1), d);  // just below the next one
+        }
+    uint64_t z = seed;
+    for (int64_t i = 0; i < n_random; i++) {
+        z = tk::rng_mix(z + 0x9E3779B97F4A7C15ull);
+        const uint32_t n = (uint32_t)(z >> 33), d = (uint32_t)(tk::rng_mix(z) >> (33 + (z & 31) % 30));
+        check(n, d);
+    }
+    return bad;
+}
+
 int hostsim_check_qnodes(const TakeSceneDesc *desc, int64_t *out) {
     HostScene<float> hs;
     std::string err = prepare_scene<float>(*desc, 0, 2, hs);

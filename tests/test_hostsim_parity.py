@@ -195,3 +195,17 @@ def test_compressed_nodes_on_a_large_soup_and_scale_mixing_fallback(fmt, width):
     sd.add_mesh(big, np.array([[0, 1, 2]], np.int32), 0)
     slots, bad, diff, infl, in_use, w = _check_qnodes(sd, fmt)
     assert in_use == 0 and infl / 1e6 > 1.10 and w == 4
+
+
+def test_slot_to_pixel_division_by_reciprocal_is_exact():
+    """every shade round turns a path slot into (sample, row, column) with two divisions by launch constants; the device
+    code multiplies by their reciprocals and corrects by one (tk_integrate.h::divmod_u31) — checked against the integer
+    division on ~100k edge pairs around the powers of two and 5 M random pairs below 2^31"""
+    import ctypes as C
+
+    from helpers import hostsim
+
+    L = hostsim()
+    L.hostsim_check_divmod.argtypes = [C.c_int64, C.c_uint64]
+    L.hostsim_check_divmod.restype = C.c_int64
+    assert L.hostsim_check_divmod(5_000_000, 12345) == 0
