@@ -98,10 +98,11 @@ template <class R> struct RecordView {
 #ifndef TK_SHADE_WAVES_F64
 #define TK_SHADE_WAVES_F64 0
 #endif
-// (the f32 cap applies to the Diffuse instance of the default integrator — the one the headline workload runs; the
-// other tags would pay for a cap with scratch)
+// (the f32 cap applies to the Diffuse instance of the default integrator — the one the headline workload runs — and to
+// the Disney stubs that clone it: 97 VGPRs without it, 96 and no scratch with it; the other tags would pay with scratch)
 template <class R, int TAG, bool ALT> constexpr int shade_waves() {
-    const int w = sizeof(R) == 4 ? ((TAG == 0 && !ALT) ? TK_SHADE_WAVES_F32 : 0) : TK_SHADE_WAVES_F64;
+    const bool lambert = TAG == 0 || TAG == 7 || TAG == 8 || TAG == 10 || TAG == 11;  // Diffuse and the Disney stubs that clone it
+    const int w = sizeof(R) == 4 ? ((lambert && !ALT) ? TK_SHADE_WAVES_F32 : 0) : TK_SHADE_WAVES_F64;
     return w > 0 ? w : 1;
 }
 template <class R, int TAG, bool ALT = false>
